@@ -1,0 +1,121 @@
+"""ctypes binding of ``libgnnepcsaft_hip.so`` (include/gnx.h).  No fallback: if the HIP library is missing or fails to
+load, importing the compute path raises — the product never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libgnnepcsaft_hip.so"
+
+GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
+POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
+K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
+    K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD = range(11)
+
+
+class GnxError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"gnx status {status}: {msg}")
+        self.status = status
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("rowscale", C.c_void_p), ("b", C.c_void_p),
+                ("ldb", C.c_int64), ("k", C.c_int32), ("_pad", C.c_int32)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# every symbol include/gnx.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "gnx_create": (_i32, [C.POINTER(_vp), _i32]),
+    "gnx_destroy": (_i32, [_vp]),
+    "gnx_set_stream": (_i32, [_vp, _vp]),
+    "gnx_last_error": (C.c_char_p, []),
+    "gnx_abi_version": (_i32, []),
+    "gnx_prof_begin": (_i32, [_vp, _i32]),
+    "gnx_prof_end": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gnx_pack_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "gnx_pack_csr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "gnx_feature_code": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _vp, _vp, _vp, _sz]),
+    "gnx_graph_ptr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _sz]),
+    "gnx_degree_scalers": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
+    "gnx_embed_sum_fwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _vp, _i32, _vp]),
+    "gnx_embed_sum_bwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _i32, _vp, _i32, _vp]),
+    "gnx_check_range": (_i32, [_vp]),
+    "gnx_gemm": (_i32, [_vp, _i32, C.POINTER(GemmSeg), _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
+    "gnx_gemm_wgrad": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "gnx_edge_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gnx_pna_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gnx_gine_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp,
+                                      _vp]),
+    "gnx_segment_pool_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gnx_segment_pool_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gnx_batchnorm_workspace_bytes": (_sz, [_i64, _i32]),
+    "gnx_batchnorm_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                 _sz]),
+    "gnx_batchnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz]),
+    "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),
+    "gnx_clip_rows": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_handles: Dict[int, int] = {}
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise ImportError(f"{_LIB_PATH} is missing: build it with `python -m gnnepcsaft_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnx_abi_version() != 1:
+        raise ImportError(f"ABI version mismatch: library {lib.gnx_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().gnx_last_error().decode(errors="replace")
+
+
+def check(status: int) -> None:
+    if status != GNX_OK:
+        raise GnxError(status, last_error())
+
+
+def handle(device: torch.device) -> int:
+    """Opaque gnx_handle* for a CUDA(HIP) device, bound to torch's current stream on that device."""
+    if device.type != "cuda":
+        raise GnxError(GNX_E_INVALID, f"gnnepcsaft_amd kernels need a HIP device tensor, got {device}; there is no CPU "
+                                      "fallback")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    lib = load()
+    h = _handles.get(idx)
+    if h is None:
+        out = _vp()
+        check(lib.gnx_create(C.byref(out), idx))
+        h = out.value
+        _handles[idx] = h
+    check(lib.gnx_set_stream(h, torch.cuda.current_stream(idx).cuda_stream))
+    return h

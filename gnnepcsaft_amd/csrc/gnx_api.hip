@@ -1,0 +1,135 @@
+// Handle lifecycle, error text, profiling hook, tiny elementwise helpers.
+#include "gnx_common.hpp"
+
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void gnx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* gnx_last_error(void) { return g_err; }
+extern "C" int32_t gnx_abi_version(void) { return GNX_ABI_VERSION; }
+
+extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
+  GNX_CHECK_ARG(out != nullptr, "gnx_create: out is NULL");
+  int count = 0;
+  GNX_HIP(hipGetDeviceCount(&count));
+  GNX_CHECK_ARG(device >= 0 && device < count, "gnx_create: device %d not in [0,%d)", device, count);
+  GNX_HIP(hipSetDevice(device));
+  gnx_handle* h = new gnx_handle();
+  h->device = device;
+  hipError_t e = hipMalloc(&h->d_flag, 256);
+  if (e == hipSuccess) e = hipMalloc(&h->d_scratch, 4096);
+  if (e == hipSuccess) e = hipMemset(h->d_flag, 0, 256);
+  if (e != hipSuccess) {
+    gnx_set_error("gnx_create: %s", hipGetErrorString(e));
+    delete h;
+    return GNX_E_HIP;
+  }
+  *out = h;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_destroy(gnx_handle* h) {
+  if (!h) return GNX_OK;
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  (void)hipFree(h->d_flag);
+  (void)hipFree(h->d_scratch);
+  delete h;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_set_stream(gnx_handle* h, void* hip_stream) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_set_stream: handle is NULL");
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return GNX_OK;
+}
+
+int32_t gnx_read_flag(gnx_handle* h, int* value) {
+  int v = 0;
+  GNX_HIP(hipMemcpyAsync(&v, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GNX_HIP(hipStreamSynchronize(h->stream));
+  if (v != 0) GNX_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+  *value = v;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_check_range(gnx_handle* h) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_check_range: handle is NULL");
+  int v = 0;
+  int32_t st = gnx_read_flag(h, &v);
+  if (st != GNX_OK) return st;
+  if (v != 0) {
+    gnx_set_error("integer input out of range:%s%s%s%s%s", (v & 1) ? " edge_index holds a node id outside [0,N);" : "",
+                  (v & 2) ? " edge/node feature outside its vocabulary;" : "",
+                  (v & 4) ? " batch holds a graph id outside [0,B);" : "", (v & 8) ? " batch is not sorted;" : "",
+                  (v & 16) ? " embedding index outside its table;" : "");
+    return GNX_E_RANGE;
+  }
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_prof_begin(gnx_handle* h, int32_t kid) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_prof_begin: handle is NULL");
+  GNX_CHECK_ARG(kid >= 0 && kid < GNX_K_COUNT, "gnx_prof_begin: bad kernel id %d", kid);
+  h->prof_kid = kid;
+  h->ev_used = 0;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_prof_end(gnx_handle* h, int64_t* launches, double* total_ms) {
+  GNX_CHECK_ARG(h != nullptr && launches != nullptr && total_ms != nullptr, "gnx_prof_end: NULL argument");
+  GNX_HIP(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0.f;
+    GNX_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += ms;
+    ++n;
+  }
+  *launches = n;
+  *total_ms = tot;
+  h->prof_kid = GNX_K_NONE;
+  h->ev_used = 0;
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_fill(float* __restrict__ p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v) {
+  GNX_CHECK_ARG(h && (p || n == 0) && n >= 0, "gnx_fill: bad argument");
+  if (n == 0) return GNX_OK;
+  int blocks = (int)(gnx_cdiv(n, 256) < 2048 ? gnx_cdiv(n, 256) : 2048);
+  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, h->stream, p, n, v);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+__global__ void k_clip_rows(const float* __restrict__ x, int64_t M, int P, const float* __restrict__ lo,
+                            const float* __restrict__ hi, float* __restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * P) return;
+  int c = (int)(i % P);
+  y[i] = fminf(fmaxf(x[i], lo[c]), hi[c]);
+}
+
+extern "C" int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo,
+                                 const float* hi, float* y) {
+  GNX_CHECK_ARG(h && x && lo && hi && y && M >= 0 && P > 0, "gnx_clip_rows: bad argument");
+  if (M == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_clip_rows, dim3((unsigned)gnx_cdiv(M * P, 256)), dim3(256), 0, h->stream, x, M, (int)P, lo, hi,
+                     y);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

@@ -1,0 +1,81 @@
+// Internal helpers shared by the gnx_*.hip translation units (gfx950 only; no dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "gnx.h"
+
+struct gnx_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // sticky device-side range flag + small scratch (handle state, not tensor memory)
+  int* d_flag = nullptr;
+  float* d_scratch = nullptr;  // 4 KiB
+  // profiling
+  int prof_kid = GNX_K_NONE;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+};
+
+void gnx_set_error(const char* fmt, ...);
+
+#define GNX_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      gnx_set_error(__VA_ARGS__);         \
+      return GNX_E_INVALID;               \
+    }                                     \
+  } while (0)
+
+#define GNX_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      gnx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));      \
+      return GNX_E_HIP;                                                                        \
+    }                                                                                          \
+  } while (0)
+
+#define GNX_LAUNCH_CHECK()                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = hipGetLastError();                                                         \
+    if (e_ != hipSuccess) {                                                                    \
+      gnx_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_));  \
+      return GNX_E_HIP;                                                                        \
+    }                                                                                          \
+  } while (0)
+
+// Records an event pair around the launches issued while it is alive, if the handle profiles kernel `kid`.
+struct gnx_prof_scope {
+  gnx_handle* h;
+  bool on;
+  gnx_prof_scope(gnx_handle* h_, int kid) : h(h_), on(h_->prof_kid == kid && kid != GNX_K_NONE) {
+    if (on) mark();
+  }
+  ~gnx_prof_scope() {
+    if (on) mark();
+  }
+  void mark() {
+    if (h->ev_used == h->ev.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {
+        on = false;
+        return;
+      }
+      h->ev.push_back(e);
+    }
+    (void)hipEventRecord(h->ev[h->ev_used++], h->stream);
+  }
+};
+
+static inline int64_t gnx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// reads + clears the sticky range flag (synchronises the stream)
+int32_t gnx_read_flag(gnx_handle* h, int* value);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,0 +1,141 @@
+// AtomEncoder / BondEncoder [3P ogb]: sum of K embedding rows, and the embedding_dense_backward scatter-add into
+// tiny tables (174 / 13 / 60 rows) done in LDS-privatised form instead of 10^5 contending global atomics.
+#include "gnx_common.hpp"
+
+struct offs_t {
+  int o[18];
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_embed_fwd(const int64_t* __restrict__ idx, int64_t N, int K, offs_t offs,
+                                                   const float* __restrict__ table, int H, float* __restrict__ out,
+                                                   int* __restrict__ flag) {
+  const int G = H / VEC;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * G) return;
+  int64_t n = t / G;
+  int c = (int)(t % G) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int64_t f = idx[n * K + k];
+    int rows = offs.o[k + 1] - offs.o[k];
+    if (f < 0 || f >= rows) {
+      if (c == 0) atomicOr(flag, 16);
+      f = 0;
+    }
+    const float* row = table + (int64_t)(offs.o[k] + (int)f) * H + c;
+    if constexpr (VEC == 4) {
+      f32x4 r = *reinterpret_cast<const f32x4*>(row);
+      acc[0] += r.x;
+      acc[1] += r.y;
+      acc[2] += r.z;
+      acc[3] += r.w;
+    } else {
+      acc[0] += row[0];
+    }
+  }
+  float* o = out + n * H + c;
+  if constexpr (VEC == 4) {
+    f32x4 r = {acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(o) = r;
+  } else {
+    o[0] = acc[0];
+  }
+}
+
+extern "C" int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
+                                     const float* table, int32_t H, float* out) {
+  GNX_CHECK_ARG(h && offsets && table && K > 0 && K <= 16 && H > 0 && N >= 0, "gnx_embed_sum_fwd: bad argument");
+  GNX_CHECK_ARG(N == 0 || (idx && out), "gnx_embed_sum_fwd: NULL array with N>0");
+  if (N == 0) return GNX_OK;
+  offs_t o;
+  for (int k = 0; k <= 17; ++k) o.o[k] = offsets[k <= K ? k : K];
+  if (H % 4 == 0) {
+    int64_t threads = N * (H / 4);
+    hipLaunchKernelGGL(k_embed_fwd<4>, dim3((unsigned)gnx_cdiv(threads, 256)), dim3(256), 0, h->stream, idx, N, (int)K,
+                       o, table, (int)H, out, h->d_flag);
+  } else {
+    int64_t threads = N * H;
+    hipLaunchKernelGGL(k_embed_fwd<1>, dim3((unsigned)gnx_cdiv(threads, 256)), dim3(256), 0, h->stream, idx, N, (int)K,
+                       o, table, (int)H, out, h->d_flag);
+  }
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dtable[R, H] += sum over rows n, features k of dout[n, :] at row offs[k]+idx[n,k].
+// grid = (row chunks, column slabs of CW).  Block: 256 threads = (256/CW) row lanes x CW columns.
+// LDS table R x CW accumulated with ds_add_f32, flushed with one global atomic per touched element.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restrict__ idx, int64_t N, int K, offs_t offs,
+                                                           int R, const float* __restrict__ dout, int H, int CW,
+                                                           int64_t rows_per_block, float* __restrict__ dtable) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < R * CW; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const int c = tid % CW;
+  const int rl = tid / CW;
+  const int RL = 256 / CW;
+  const int col = blockIdx.y * CW + c;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > N) r1 = N;
+  if (col < H) {
+    for (int64_t n = r0 + rl; n < r1; n += RL) {
+      float g = dout[n * H + col];
+      for (int k = 0; k < K; ++k) {
+        int64_t f = (int64_t)idx[n * K + k];
+        int rows = offs.o[k + 1] - offs.o[k];
+        if (f < 0 || f >= rows) continue;  // flagged in forward
+        atomicAdd(&lds[(offs.o[k] + (int)f) * CW + c], g);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < R * CW; i += 256) {
+    int r = i / CW, cc = blockIdx.y * CW + (i % CW);
+    float v = lds[i];
+    if (cc < H && v != 0.f) atomicAdd(&dtable[(int64_t)r * H + cc], v);
+  }
+}
+
+template <typename IdxT>
+static int32_t launch_table_scatter_add(gnx_handle* h, const IdxT* idx, int64_t N, int K, const int32_t* offsets, int R,
+                                        const float* dout, int H, float* dtable) {
+  offs_t o;
+  for (int k = 0; k <= 17; ++k) o.o[k] = offsets[k <= K ? k : K];
+  int CW = 64;
+  while ((size_t)R * CW * sizeof(float) > 64 * 1024 && CW > 8) CW >>= 1;
+  GNX_CHECK_ARG((size_t)R * CW * sizeof(float) <= 64 * 1024, "table scatter-add: %d rows do not fit the LDS tile", R);
+  int slabs = (int)gnx_cdiv(H, CW);
+  // enough blocks to fill the chip, at least 256 rows each so the flush stays a small fraction
+  int64_t rows_per_block = gnx_cdiv(N, gnx_cdiv(1024, slabs));
+  if (rows_per_block < 256) rows_per_block = 256;
+  int64_t chunks = gnx_cdiv(N, rows_per_block);
+  hipLaunchKernelGGL(k_table_scatter_add<IdxT>, dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
+                     (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
+                                     int32_t R, const float* dout, int32_t H, float* dtable) {
+  GNX_CHECK_ARG(h && offsets && dtable && K > 0 && K <= 16 && H > 0 && R > 0 && N >= 0, "gnx_embed_sum_bwd: bad argument");
+  GNX_CHECK_ARG(N == 0 || (idx && dout), "gnx_embed_sum_bwd: NULL array with N>0");
+  GNX_CHECK_ARG(offsets[K] == R, "gnx_embed_sum_bwd: offsets[K]=%d != R=%d", offsets[K], R);
+  if (N == 0) return GNX_OK;
+  return launch_table_scatter_add<int64_t>(h, idx, N, K, offsets, R, dout, H, dtable);
+}
+
+// used by gnx_edge_combine_bwd / gnx_gine_aggregate_bwd (int32 codes, one table)
+int32_t gnx_code_scatter_add(gnx_handle* h, const int32_t* code, int64_t E, int R, const float* g, int H,
+                             float* dtable) {
+  if (E == 0) return GNX_OK;
+  int32_t offs[2] = {0, R};
+  return launch_table_scatter_add<int32_t>(h, code, E, 1, offs, R, g, H, dtable);
+}

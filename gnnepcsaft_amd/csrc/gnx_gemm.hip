@@ -1,0 +1,431 @@
+// Dense feature x weight contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// Shapes on this path are tall-skinny: M = #edges or #nodes (1e5..1e6), N = 32..512, K = 32..13*F.
+// Tile: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).
+// Operands are staged global -> registers -> LDS (one LDS buffer; the next K-tile's global loads are issued before the
+// MFMAs of the current one and written to LDS after them), several workgroups per CU hide the two barriers per step.
+//
+// LDS images:
+//   "row-k" image  T[row][k]  (A always; B when the weight is [n][k], i.e. NT): row stride 36 floats.  A lane (i = l&31,
+//        h = l>>5) fetches k = 8*kk + 4*h .. +3 with ONE ds_read_b128 and feeds element t to MFMA step t, i.e. MFMA step
+//        (kk,t) contracts k in {8kk+t, 8kk+4+t}: the k order inside a tile is permuted identically for A and B, which only
+//        reorders an exact-fp32 sum.  36 = 4*9 (9 odd) makes the 16 lanes of every ds_read_b128 group hit 16 distinct
+//        16-byte slots (MI355X_MICROARCH.md, LDS table).
+//   "k-row" image  T[k][col]  (B when the weight is [k][n], i.e. NN; both operands of the TN weight gradient):
+//        row stride 128 floats, read with ds_read_b32 (32 consecutive columns per half-wave: conflict-free).
+#include "gnx_common.hpp"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDK 36    // row stride of the row-k image
+#define LDN 128   // row stride of the k-row image
+#define MAX_SEGS 4
+
+struct seg_dev {
+  const float* a;
+  const float* rs;
+  const float* b;
+  int64_t lda;
+  int64_t ldb;
+  int k;
+  int vec_a;  // 1: float4 loads allowed on A (16B-aligned rows)
+  int vec_b;
+};
+
+struct gemm_args {
+  seg_dev seg[MAX_SEGS];
+  int nseg;
+  int64_t M;
+  int N;
+  const float* bias;
+  const float* mask;
+  int64_t ldmask;
+  float* C;
+  int64_t ldc;
+  int relu;
+  int accumulate;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int valid) {
+  // valid = number of in-range elements (0..4) starting at p
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+    if (valid > 0) v.x = p[0];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    if (valid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+template <bool B_TRANS>
+__global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[B_TRANS ? BN * LDK : BK * LDN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging registers
+  f32x4 ra[4], rb[4];
+
+  // loader geometry for the row-k image: 8 lanes cover one 128-B row, 32 rows per pass, 4 passes
+  const int lr = tid >> 3;        // 0..31
+  const int lk = (tid & 7) * 4;   // 0..28
+  // loader geometry for the k-row image (NN B): 32 lanes cover 128 columns, 8 k-rows per pass, 4 passes
+  const int br = tid >> 5;        // 0..7
+  const int bc = (tid & 31) * 4;  // 0..124
+
+  auto load_tile = [&](const seg_dev& s, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = lr + 32 * i;
+      int64_t gm = m0 + r;
+      int kv = s.k - (k0 + lk);
+      kv = gm < g.M ? kv : 0;
+      f32x4 v = ld4(s.a + gm * s.lda + k0 + lk, s.vec_a, kv);
+      if (s.rs != nullptr && kv > 0) {
+        float sc = s.rs[gm];
+        v.x *= sc;
+        v.y *= sc;
+        v.z *= sc;
+        v.w *= sc;
+      }
+      ra[i] = v;
+    }
+    if (B_TRANS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = lr + 32 * i;
+        int gn = n0 + r;
+        int kv = s.k - (k0 + lk);
+        kv = gn < g.N ? kv : 0;
+        rb[i] = ld4(s.b + (int64_t)gn * s.ldb + k0 + lk, s.vec_b, kv);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int kr = br + 8 * i;
+        int nv = g.N - (n0 + bc);
+        nv = (k0 + kr) < s.k ? nv : 0;
+        rb[i] = ld4(s.b + (int64_t)(k0 + kr) * s.ldb + n0 + bc, s.vec_b, nv);
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int r = lr + 32 * i;
+      *reinterpret_cast<f32x4*>(&As[r * LDK + lk]) = ra[i];
+    }
+    if (B_TRANS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = lr + 32 * i;
+        *reinterpret_cast<f32x4*>(&Bs[r * LDK + lk]) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int kr = br + 8 * i;
+        *reinterpret_cast<f32x4*>(&Bs[kr * LDN + bc]) = rb[i];
+      }
+    }
+  };
+
+  // flattened (segment, k0) tile list
+  int s_idx = 0, k0 = 0;
+  load_tile(g.seg[0], 0);
+  bool more = true;
+  while (more) {
+    __syncthreads();  // previous compute finished reading LDS
+    store_tile();
+    __syncthreads();
+    // advance and prefetch the next tile into registers
+    k0 += BK;
+    if (k0 >= g.seg[s_idx].k) {
+      ++s_idx;
+      k0 = 0;
+    }
+    more = s_idx < g.nseg;
+    if (more) load_tile(g.seg[s_idx], k0);
+
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + mi * 32 + li) * LDK + kk * 8 + 4 * lh]);
+      if (B_TRANS) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          b[ni] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + ni * 32 + li) * LDK + kk * 8 + 4 * lh]);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float* p = &Bs[(kk * 8 + 4 * lh) * LDN + wn * 64 + ni * 32 + li];
+          b[ni].x = p[0];
+          b[ni].y = p[LDN];
+          b[ni].z = p[2 * LDN];
+          b[ni].w = p[3 * LDN];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      int gc = n0 + wn * 64 + ni * 32 + li;
+      if (gc >= g.N) continue;
+      float bv = g.bias ? g.bias[gc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t gr = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (gr >= g.M) continue;
+        float v = acc[mi][ni][r] + bv;
+        float* cp = g.C + gr * g.ldc + gc;
+        if (g.accumulate) v += *cp;
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.mask) v = (g.mask[gr * g.ldmask + gc] > 0.f) ? v : 0.f;
+        *cp = v;
+      }
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
+                            const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
+  GNX_CHECK_ARG(h && segs && C, "gnx_gemm: NULL argument");
+  GNX_CHECK_ARG(nseg >= 1 && nseg <= MAX_SEGS, "gnx_gemm: nseg=%d not in [1,%d]", nseg, MAX_SEGS);
+  GNX_CHECK_ARG(M >= 0 && N > 0 && ldc >= N, "gnx_gemm: bad shape M=%lld N=%d ldc=%lld", (long long)M, N, (long long)ldc);
+  GNX_CHECK_ARG(!((flags & GNX_GEMM_RELU) && (flags & GNX_GEMM_ACCUMULATE)), "gnx_gemm: relu+accumulate rejected");
+  GNX_CHECK_ARG(mask == nullptr || ldmask >= N, "gnx_gemm: ldmask < N");
+  if (M == 0) return GNX_OK;
+  const bool bt = (flags & GNX_GEMM_B_TRANS) != 0;
+  gemm_args g;
+  for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  for (int s = 0; s < nseg; ++s) {
+    const gnx_gemm_seg& in = segs[s];
+    GNX_CHECK_ARG(in.a && in.b && in.k > 0, "gnx_gemm: segment %d: NULL operand or k<=0", s);
+    GNX_CHECK_ARG(in.lda >= in.k, "gnx_gemm: segment %d: lda < k", s);
+    GNX_CHECK_ARG(bt ? in.ldb >= in.k : in.ldb >= N, "gnx_gemm: segment %d: ldb too small", s);
+    seg_dev d;
+    d.a = in.a;
+    d.rs = in.rowscale;
+    d.b = in.b;
+    d.lda = in.lda;
+    d.ldb = in.ldb;
+    d.k = in.k;
+    d.vec_a = aligned16(in.a) && (in.lda % 4 == 0);
+    d.vec_b = aligned16(in.b) && (in.ldb % 4 == 0);
+    g.seg[s] = d;
+  }
+  g.nseg = nseg;
+  g.M = M;
+  g.N = N;
+  g.bias = bias;
+  g.mask = mask;
+  g.ldmask = ldmask;
+  g.C = C;
+  g.ldc = ldc;
+  g.relu = (flags & GNX_GEMM_RELU) ? 1 : 0;
+  g.accumulate = (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0;
+  dim3 grid((unsigned)gnx_cdiv(M, BM), (unsigned)gnx_cdiv(N, BN));
+  gnx_prof_scope prof(h, GNX_K_GEMM);
+  if (bt)
+    hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, h->stream, g);
+  else
+    hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient  dW[n,k] += sum_m dC[m,n] * rs[m]*A[m,k]   (both operands k-row images: the contraction index m is the
+// row of both).  grid = (M chunks, n tiles, k tiles); fp32 atomics into dW; the k-tile-0 workgroups also reduce dbias.
+// ---------------------------------------------------------------------------------------------------------------
+struct wgrad_args {
+  const float* X;  // dC [M, N]
+  int64_t ldx;
+  const float* Y;  // A  [M, K]
+  int64_t ldy;
+  const float* rs;
+  int64_t M;
+  int N, K;
+  float* dW;
+  int64_t lddw;
+  float* dbias;
+  int64_t rows_per_block;
+  int vec_x, vec_y;
+};
+
+__global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
+  __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
+  __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;  // dW row tile (output features)
+  const int c0 = blockIdx.z * BN;  // dW col tile (input features)
+  const int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
+  int64_t r_end = r_begin + g.rows_per_block;
+  if (r_end > g.M) r_end = g.M;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;  // threads 0..127: column n0+tid of dC
+
+  const int br = tid >> 5;
+  const int bc = (tid & 31) * 4;
+  f32x4 rx[4], ry[4];
+
+  auto load_tile = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t gm = r0 + br + 8 * i;
+      bool rv = gm < r_end;
+      int nv = rv ? g.N - (n0 + bc) : 0;
+      rx[i] = ld4(g.X + gm * g.ldx + n0 + bc, g.vec_x, nv);
+      int kv = rv ? g.K - (c0 + bc) : 0;
+      f32x4 v = ld4(g.Y + gm * g.ldy + c0 + bc, g.vec_y, kv);
+      if (g.rs != nullptr && rv) {
+        float sc = g.rs[gm];
+        v.x *= sc;
+        v.y *= sc;
+        v.z *= sc;
+        v.w *= sc;
+      }
+      ry[i] = v;
+    }
+  };
+
+  int64_t r0 = r_begin;
+  if (r0 < r_end) load_tile(r0);
+  while (r0 < r_end) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int kr = br + 8 * i;
+      *reinterpret_cast<f32x4*>(&Xs[kr * LDN + bc]) = rx[i];
+      *reinterpret_cast<f32x4*>(&Ys[kr * LDN + bc]) = ry[i];
+    }
+    __syncthreads();
+    r0 += BK;
+    if (r0 < r_end) load_tile(r0);
+
+    if (g.dbias != nullptr && blockIdx.z == 0 && tid < BN) {
+#pragma unroll 8
+      for (int r = 0; r < BK; ++r) bsum += Xs[r * LDN + tid];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float* p = &Xs[(kk * 8 + 4 * lh) * LDN + wm * 64 + mi * 32 + li];
+        a[mi].x = p[0];
+        a[mi].y = p[LDN];
+        a[mi].z = p[2 * LDN];
+        a[mi].w = p[3 * LDN];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const float* p = &Ys[(kk * 8 + 4 * lh) * LDN + wn * 64 + ni * 32 + li];
+        b[ni].x = p[0];
+        b[ni].y = p[LDN];
+        b[ni].z = p[2 * LDN];
+        b[ni].w = p[3 * LDN];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      int gc = c0 + wn * 64 + ni * 32 + li;
+      if (gc >= g.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int gr = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (gr >= g.N) continue;
+        atomicAdd(g.dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
+      }
+    }
+  if (g.dbias != nullptr && blockIdx.z == 0 && tid < BN && n0 + tid < g.N) atomicAdd(g.dbias + n0 + tid, bsum);
+}
+
+extern "C" int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
+                                  const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw,
+                                  float* dbias) {
+  GNX_CHECK_ARG(h && dC && A && dW, "gnx_gemm_wgrad: NULL argument");
+  GNX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lddc >= N && lda >= K && lddw >= K, "gnx_gemm_wgrad: bad shape");
+  if (M == 0) return GNX_OK;
+  wgrad_args g;
+  g.X = dC;
+  g.ldx = lddc;
+  g.Y = A;
+  g.ldy = lda;
+  g.rs = rowscale;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.dW = dW;
+  g.lddw = lddw;
+  g.dbias = dbias;
+  g.vec_x = aligned16(dC) && (lddc % 4 == 0);
+  g.vec_y = aligned16(A) && (lda % 4 == 0);
+  int64_t tiles = gnx_cdiv(N, BN) * gnx_cdiv(K, BN);
+  // aim for ~512 workgroups; at least 128 rows each (4 K-steps) so the atomic flush stays amortised
+  int64_t chunks = gnx_cdiv(512, tiles);
+  int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
+  if (rows < 128) rows = 128;
+  g.rows_per_block = rows;
+  dim3 grid((unsigned)gnx_cdiv(M, rows), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
+  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
+  hipLaunchKernelGGL(k_gemm_wgrad, grid, dim3(256), 0, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

@@ -1,0 +1,305 @@
+// BatchNorm1d (+ReLU) over the rows of a [M, H] activation (PyG BatchNorm wraps torch.nn.BatchNorm1d; the readout MLP
+// uses BatchNorm1d directly), and the APE-Huber loss.  HBM-bound column reductions + elementwise passes.
+//
+// Statistics: single pass of SHIFTED sums (pivot = row 0 of every column) so that var = E[(x-k)^2] - E[x-k]^2 does not
+// cancel catastrophically; per-chunk partials are written to the workspace and folded by one thread per column in chunk
+// order -> deterministic, no atomics.
+#include "gnx_common.hpp"
+
+#define BN_ROWS_PER_BLOCK 256
+
+// workspace layout (floats): [2*H] alpha/beta' | [nchunk * 2 * H] partials
+extern "C" size_t gnx_batchnorm_workspace_bytes(int64_t M, int32_t H) {
+  if (M < 0) M = 0;
+  size_t chunks = (size_t)gnx_cdiv(M > 0 ? M : 1, BN_ROWS_PER_BLOCK);
+  return sizeof(float) * ((size_t)4 * H + chunks * 2 * (size_t)H) + 256;
+}
+
+// grid = (chunks, column blocks of 64); block = 64 columns x 4 row lanes
+__global__ void __launch_bounds__(256) k_bn_partial(const float* __restrict__ x, int64_t M, int H,
+                                                    float* __restrict__ part) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + cx;
+  int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+  int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  float a1 = 0.f, a2 = 0.f;
+  if (col < H) {
+    const float k = x[col];
+    for (int64_t r = r0 + ry; r < r1; r += 4) {
+      float v = x[r * H + col] - k;
+      a1 += v;
+      a2 += v * v;
+    }
+  }
+  s1[ry][cx] = a1;
+  s2[ry][cx] = a2;
+  __syncthreads();
+  if (ry == 0 && col < H) {
+    float t1 = (s1[0][cx] + s1[1][cx]) + (s1[2][cx] + s1[3][cx]);
+    float t2 = (s2[0][cx] + s2[1][cx]) + (s2[2][cx] + s2[3][cx]);
+    part[((int64_t)blockIdx.x * 2 + 0) * H + col] = t1;
+    part[((int64_t)blockIdx.x * 2 + 1) * H + col] = t2;
+  }
+}
+
+// one thread per column: fold chunks, derive mean/rstd, update running stats, emit alpha/beta'
+__global__ void k_bn_finalize(const float* __restrict__ x, const float* __restrict__ part, int64_t chunks, int64_t M,
+                              int H, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                              float eps, int training, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                              float* __restrict__ ab) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float mean, var;
+  if (training) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int64_t b = 0; b < chunks; ++b) {
+      t1 += part[(b * 2 + 0) * H + c];
+      t2 += part[(b * 2 + 1) * H + c];
+    }
+    const float inv = 1.0f / (float)M;
+    const float d = t1 * inv;
+    mean = x[c] + d;
+    var = fmaxf(t2 * inv - d * d, 0.f);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+      float unb = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  float rstd = 1.0f / sqrtf(var + eps);
+  if (save_mean) save_mean[c] = mean;
+  if (save_rstd) save_rstd[c] = rstd;
+  float a = rstd * (gamma ? gamma[c] : 1.f);
+  ab[c] = a;
+  ab[H + c] = (beta ? beta[c] : 0.f) - mean * a;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, int64_t total, int H,
+                                                  const float* __restrict__ ab, int relu, float* __restrict__ y) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
+  for (; i < total; i += stride) {
+    int c = (int)(i % H);
+    if constexpr (VEC == 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+      f32x4 a = *reinterpret_cast<const f32x4*>(ab + c);
+      f32x4 b = *reinterpret_cast<const f32x4*>(ab + H + c);
+      f32x4 o = {v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w};
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f);
+        o.y = fmaxf(o.y, 0.f);
+        o.z = fmaxf(o.z, 0.f);
+        o.w = fmaxf(o.w, 0.f);
+      }
+      *reinterpret_cast<f32x4*>(y + i) = o;
+    } else {
+      float o = x[i] * ab[c] + ab[H + c];
+      y[i] = relu ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
+extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, int32_t H, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, int32_t training, int32_t relu, float* y, float* save_mean,
+                                     float* save_rstd, void* ws, size_t ws_bytes) {
+  GNX_CHECK_ARG(h && H > 0 && M >= 0, "gnx_batchnorm_fwd: bad argument");
+  if (M == 0) return GNX_OK;
+  GNX_CHECK_ARG(x && y && ws, "gnx_batchnorm_fwd: NULL argument");
+  GNX_CHECK_ARG(training || (running_mean && running_var), "gnx_batchnorm_fwd: eval mode needs running stats");
+  if (ws_bytes < gnx_batchnorm_workspace_bytes(M, H)) {
+    gnx_set_error("gnx_batchnorm_fwd: workspace %zu < %zu", ws_bytes, gnx_batchnorm_workspace_bytes(M, H));
+    return GNX_E_WORKSPACE;
+  }
+  float* ab = reinterpret_cast<float*>(ws);
+  float* part = ab + 4 * (size_t)H;
+  int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
+  gnx_prof_scope prof(h, GNX_K_BN_FWD);
+  if (training) {
+    hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, x, M,
+                       (int)H, part);
+    GNX_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)gnx_cdiv(H, 64)), dim3(64), 0, h->stream, x, part, chunks, M, (int)H,
+                     gamma, beta, running_mean, running_var, momentum, eps, (int)training, save_mean, save_rstd, ab);
+  GNX_LAUNCH_CHECK();
+  int64_t total = M * H;
+  if (H % 4 == 0) {
+    int64_t blocks = gnx_cdiv(total / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_bn_apply<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, x, total, (int)H, ab, (int)relu, y);
+  } else {
+    int64_t blocks = gnx_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_bn_apply<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, x, total, (int)H, ab, (int)relu, y);
+  }
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: g = dy * (y>0 if relu); dbeta = sum g; dgamma = sum g*xhat; dx = gamma*rstd*(g - dbeta/M - xhat*dgamma/M)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ y, int64_t M, int H,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int relu, float* __restrict__ part) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + cx;
+  int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+  int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  float a1 = 0.f, a2 = 0.f;
+  if (col < H) {
+    const float mu = mean[col], rs = rstd[col];
+    for (int64_t r = r0 + ry; r < r1; r += 4) {
+      float g = dy[r * H + col];
+      if (relu && !(y[r * H + col] > 0.f)) g = 0.f;
+      a1 += g;
+      a2 += g * ((x[r * H + col] - mu) * rs);
+    }
+  }
+  s1[ry][cx] = a1;
+  s2[ry][cx] = a2;
+  __syncthreads();
+  if (ry == 0 && col < H) {
+    part[((int64_t)blockIdx.x * 2 + 0) * H + col] = (s1[0][cx] + s1[1][cx]) + (s1[2][cx] + s1[3][cx]);
+    part[((int64_t)blockIdx.x * 2 + 1) * H + col] = (s2[0][cx] + s2[1][cx]) + (s2[2][cx] + s2[3][cx]);
+  }
+}
+
+// coef[c] = (gamma*rstd, dbeta/M, dgamma/M * rstd... ) stored as 4 rows of H: k0 = gamma*rstd, k1 = dbeta/M, k2 = dgamma/M
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int64_t chunks, int64_t M, int H,
+                                  const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int64_t b = 0; b < chunks; ++b) {
+    t1 += part[(b * 2 + 0) * H + c];
+    t2 += part[(b * 2 + 1) * H + c];
+  }
+  if (dbeta) dbeta[c] += t1;
+  if (dgamma) dgamma[c] += t2;
+  const float inv = 1.0f / (float)M;
+  coef[c] = (gamma ? gamma[c] : 1.f) * rstd[c];
+  coef[H + c] = t1 * inv;
+  coef[2 * H + c] = t2 * inv;
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ y, int64_t total, int H,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ coef, int relu, float* __restrict__ dx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    int c = (int)(i % H);
+    float g = dy[i];
+    if (relu && !(y[i] > 0.f)) g = 0.f;
+    float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = coef[c] * (g - coef[H + c] - xh * coef[2 * H + c]);
+  }
+}
+
+extern "C" int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float* x, const float* y, int64_t M,
+                                     int32_t H, const float* gamma, const float* save_mean, const float* save_rstd,
+                                     int32_t relu, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes) {
+  GNX_CHECK_ARG(h && H > 0 && M >= 0, "gnx_batchnorm_bwd: bad argument");
+  if (M == 0) return GNX_OK;
+  GNX_CHECK_ARG(dy && x && save_mean && save_rstd && dx && ws && (!relu || y), "gnx_batchnorm_bwd: NULL argument");
+  if (ws_bytes < gnx_batchnorm_workspace_bytes(M, H)) {
+    gnx_set_error("gnx_batchnorm_bwd: workspace %zu < %zu", ws_bytes, gnx_batchnorm_workspace_bytes(M, H));
+    return GNX_E_WORKSPACE;
+  }
+  float* coef = reinterpret_cast<float*>(ws);
+  float* part = coef + 4 * (size_t)H;
+  int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
+  gnx_prof_scope prof(h, GNX_K_BN_BWD);
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, dy, x,
+                     y, M, (int)H, save_mean, save_rstd, (int)relu, part);
+  GNX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)gnx_cdiv(H, 64)), dim3(64), 0, h->stream, part, chunks, M, (int)H,
+                     gamma, save_rstd, dgamma, dbeta, coef);
+  GNX_LAUNCH_CHECK();
+  int64_t total = M * H;
+  int64_t blocks = gnx_cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, h->stream, dy, x, y, total, (int)H, save_mean,
+                     save_rstd, coef, (int)relu, dx);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// APE-Huber loss + MAPE metric.  Stage 1: <=64 blocks write (huber, mape) partial sums into the handle scratch and
+// dpred; stage 2: one wave folds them in block order.
+// ---------------------------------------------------------------------------------------------------------------
+#define LOSS_MAX_BLOCKS 64
+
+__global__ void __launch_bounds__(256) k_huber_partial(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       int64_t count, float delta, float* __restrict__ part,
+                                                       float* __restrict__ dpred) {
+  __shared__ float sh[256], sm[256];
+  float ah = 0.f, am = 0.f;
+  const float inv = 1.0f / (float)count;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    float p = pred[i], t = tgt[i];
+    float a = (p - t) / t;
+    float aa = fabsf(a);
+    ah += (aa <= delta) ? 0.5f * a * a : delta * (aa - 0.5f * delta);
+    am += fabsf(p - t) / fmaxf(fabsf(t), 1.17e-06f);
+    if (dpred) {
+      float da = (aa <= delta) ? a : (a > 0.f ? delta : -delta);
+      dpred[i] = da * inv / t;
+    }
+  }
+  sh[threadIdx.x] = ah;
+  sm[threadIdx.x] = am;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      sh[threadIdx.x] += sh[threadIdx.x + off];
+      sm[threadIdx.x] += sm[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = sh[0];
+    part[blockIdx.x * 2 + 1] = sm[0];
+  }
+}
+
+__global__ void k_huber_final(const float* __restrict__ part, int blocks, int64_t count, float* __restrict__ out2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float h = 0.f, m = 0.f;
+    for (int b = 0; b < blocks; ++b) {
+      h += part[b * 2];
+      m += part[b * 2 + 1];
+    }
+    out2[0] = h / (float)count;
+    out2[1] = m / (float)count;
+  }
+}
+
+extern "C" int32_t gnx_huber_ape(gnx_handle* h, const float* pred, const float* target, int64_t count, float delta,
+                                 float* out2, float* dpred) {
+  GNX_CHECK_ARG(h && pred && target && out2 && count > 0, "gnx_huber_ape: bad argument");
+  int blocks = (int)(gnx_cdiv(count, 256) < LOSS_MAX_BLOCKS ? gnx_cdiv(count, 256) : LOSS_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_huber_partial, dim3(blocks), dim3(256), 0, h->stream, pred, target, count, delta, h->d_scratch,
+                     dpred);
+  GNX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_huber_final, dim3(1), dim3(64), 0, h->stream, h->d_scratch, blocks, count, out2);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

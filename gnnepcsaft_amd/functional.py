@@ -1,0 +1,290 @@
+"""torch.autograd.Function wrappers: each forward/backward is a hand-written sequence of gnx kernel launches.
+
+autograd is used as the tape between layers only; no torch arithmetic runs inside these functions (allocation with
+``torch.empty/zeros`` is storage plumbing).  Semantics cited per function; ``[3P]`` = torch_geometric / ogb module the
+reference wires at ``/root/reference/gnnepcsaft/train/models.py``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import GraphPack
+
+
+def _empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
+
+
+def _zeros_like(t: torch.Tensor) -> torch.Tensor:
+    return torch.zeros(t.shape, dtype=torch.float32, device=t.device)
+
+
+class EmbedSumFn(torch.autograd.Function):
+    """[3P] ogb AtomEncoder/BondEncoder.forward: sum_k Embedding_k(idx[:,k]) (models.py:205-206)."""
+
+    @staticmethod
+    def forward(ctx, idx, table, offsets):
+        ctx.save_for_backward(idx)
+        ctx.offsets = tuple(offsets)
+        return ops.embed_sum_fwd(idx, table, offsets)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return None, ops.embed_sum_bwd(idx, ctx.offsets, dout.contiguous()), None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (torch.nn.Linear / PyG Linear; readout MLP models.py:186-194)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        y = _empty(x.size(0), weight.size(0), x)
+        return ops.gemm([(x, None, weight)], y, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw = _zeros_like(weight)
+        db = torch.zeros(weight.size(0), dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+        ops.gemm_wgrad(dy, x, dw, dbias=db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm([(dy, None, weight)], _empty(x.size(0), x.size(1), x), b_trans=False)
+        return dx, dw, db
+
+
+class BatchNormFn(torch.autograd.Function):
+    """torch.nn.BatchNorm1d (PyG BatchNorm wrapper; models.py:184, 212-214) with the following F.relu fused."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+        x = x.contiguous()
+        y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.relu, ctx.training = relu, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise NotImplementedError("BatchNorm backward in eval mode is not on the reference's training path")
+        dx, dgamma, dbeta = ops.batchnorm_bwd(dy.contiguous(), x, y, gamma, mean, rstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class SegmentPoolFn(torch.autograd.Function):
+    """[3P] Sum/Mean/MaxAggregation over ``batch`` (models.py:218-225, 587-595); contiguous segments via graph_ptr."""
+
+    @staticmethod
+    def forward(ctx, x, ptr, B, mode):
+        x = x.contiguous()
+        out = ops.segment_pool_fwd(x, ptr, B, mode)
+        ctx.save_for_backward(x, out, ptr)
+        ctx.B, ctx.mode = B, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, ptr = ctx.saved_tensors
+        return ops.segment_pool_bwd(dout.contiguous(), x, out, ptr, ctx.B, ctx.mode), None, None, None
+
+
+class HuberAPEFn(torch.autograd.Function):
+    """loss = huber((pred-target)/target, 0, delta=0.01), mean reduction (models.py:89-91); also returns MAPE (:92)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, delta):
+        out2, dpred = ops.huber_ape(pred, target, delta, need_grad=True)
+        ctx.save_for_backward(dpred)
+        ctx.mark_non_differentiable(out2)
+        return out2[0], out2
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (dpred,) = ctx.saved_tensors
+        # dloss is 1 for a plain .backward(); scaling by another scalar is storage-level plumbing
+        return dpred * dloss, None, None
+
+
+class PNAConvFn(torch.autograd.Function):
+    """[3P] torch_geometric.nn.PNAConv(aggregators=[mean,min,max,std], scalers=[identity,amplification,attenuation],
+    towers=T, pre_layers, post_layers, divide_input=True) as built at models.py:445-457.
+
+    Restructured for the GPU (same sums, re-associated):
+      * pre-layer 0, ``Linear(3F->F)`` on cat([x_i, x_j, e]), is split into node-level products P = x W_i^T,
+        Q = x W_j^T and a 60-row bond table Te = (BondEmb W_enc^T + b_enc) W_e^T + b, combined per edge by a gather;
+      * the 13F-wide post-layer-0 operand [x | A | amp*A | att*A] is never materialised: it is a 4-segment product.
+    params: enc_w, enc_b, lin_w, lin_b, then per tower: pre (w, b) x pre_layers, post (w, b) x post_layers.
+    """
+
+    @staticmethod
+    def forward(ctx, x, BE, pack: GraphPack, cfg, *params):
+        T, F, pre_layers, post_layers, avg_deg_log = cfg
+        x = x.contiguous()
+        N, H = x.shape
+        E, R = pack.E, BE.size(0)
+        enc_w, enc_b, lin_w, lin_b = params[:4]
+        per = 2 * (pre_layers + post_layers)
+        pre = [[(params[4 + t * per + 2 * i], params[4 + t * per + 2 * i + 1]) for i in range(pre_layers)]
+               for t in range(T)]
+        post = [[(params[4 + t * per + 2 * (pre_layers + i)], params[4 + t * per + 2 * (pre_layers + i) + 1])
+                 for i in range(post_layers)] for t in range(T)]
+        sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+        EE = ops.gemm([(BE, None, enc_w)], _empty(R, F, x), bias=enc_b)
+        Te, P, Q = _empty(R, H, x), _empty(N, H, x), _empty(N, H, x)
+        for t in range(T):
+            W0, b0 = pre[t][0]
+            xt = x[:, sl[t]]
+            ops.gemm([(EE, None, W0[:, 2 * F:3 * F])], Te[:, sl[t]], bias=b0)
+            ops.gemm([(xt, None, W0[:, 0:F])], P[:, sl[t]])
+            ops.gemm([(xt, None, W0[:, F:2 * F])], Q[:, sl[t]])
+        h = ops.edge_combine_fwd(P, Q, Te, pack, relu=pre_layers > 1)
+        hs = [h]
+        for i in range(1, pre_layers):
+            hn = _empty(E, H, x)
+            for t in range(T):
+                Wi, bi = pre[t][i]
+                ops.gemm([(h[:, sl[t]], None, Wi)], hn[:, sl[t]], bias=bi, relu=i < pre_layers - 1)
+            h = hn
+            hs.append(h)
+        A = ops.pna_aggregate_fwd(h, pack, T, F)
+        amp, att = pack.degree_scalers(avg_deg_log)
+        z = _empty(N, H, x)
+        for t in range(T):
+            Wp, bp = post[t][0]
+            At = A[:, t * 4 * F:(t + 1) * 4 * F]
+            ops.gemm([(x[:, sl[t]], None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
+                      (At, att, Wp[:, 9 * F:13 * F])], z[:, sl[t]], bias=bp, relu=post_layers > 1)
+        zs = [z]
+        for i in range(1, post_layers):
+            zn = _empty(N, H, x)
+            for t in range(T):
+                Wi, bi = post[t][i]
+                ops.gemm([(z[:, sl[t]], None, Wi)], zn[:, sl[t]], bias=bi, relu=i < post_layers - 1)
+            z = zn
+            zs.append(z)
+        out = ops.gemm([(z, None, lin_w)], _empty(N, H, x), bias=lin_b)
+        ctx.pack, ctx.cfg = pack, cfg
+        ctx.n_h, ctx.n_z = len(hs), len(zs)
+        ctx.save_for_backward(x, BE, EE, A, amp, att, *hs, *zs, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, F, pre_layers, post_layers, _ = ctx.cfg
+        pack: GraphPack = ctx.pack
+        saved = ctx.saved_tensors
+        x, BE, EE, A, amp, att = saved[:6]
+        hs = list(saved[6:6 + ctx.n_h])
+        zs = list(saved[6 + ctx.n_h:6 + ctx.n_h + ctx.n_z])
+        params = saved[6 + ctx.n_h + ctx.n_z:]
+        N, H = x.shape
+        E, R = pack.E, BE.size(0)
+        enc_w, enc_b, lin_w, lin_b = params[:4]
+        per = 2 * (pre_layers + post_layers)
+        grads = [_zeros_like(p) for p in params]
+        d_enc_w, d_enc_b, d_lin_w, d_lin_b = grads[:4]
+
+        def pidx(t, kind, i):  # index of (w) in params/grads
+            return 4 + t * per + 2 * (i if kind == "pre" else pre_layers + i)
+
+        sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+        dout = dout.contiguous()
+        # lin
+        ops.gemm_wgrad(dout, zs[-1], d_lin_w, dbias=d_lin_b)
+        g = ops.gemm([(dout, None, lin_w)], _empty(N, H, x), b_trans=False)
+        # post layers last..1 : dgrad masked by the relu'd input activation
+        for i in range(post_layers - 1, 0, -1):
+            a_prev = zs[i - 1]
+            gn = _empty(N, H, x)
+            for t in range(T):
+                k = pidx(t, "post", i)
+                ops.gemm_wgrad(g[:, sl[t]], a_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
+                ops.gemm([(g[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=a_prev[:, sl[t]])
+            g = gn
+        # post layer 0: 4-segment weight gradient, 3-segment dA
+        dA = _empty(N, T * 4 * F, x)
+        for t in range(T):
+            k = pidx(t, "post", 0)
+            Wp, dWp = params[k], grads[k]
+            gt = g[:, sl[t]]
+            At = A[:, t * 4 * F:(t + 1) * 4 * F]
+            ops.gemm_wgrad(gt, x[:, sl[t]], dWp[:, 0:F], dbias=grads[k + 1])
+            ops.gemm_wgrad(gt, At, dWp[:, F:5 * F])
+            ops.gemm_wgrad(gt, At, dWp[:, 5 * F:9 * F], rowscale=amp)
+            ops.gemm_wgrad(gt, At, dWp[:, 9 * F:13 * F], rowscale=att)
+            ops.gemm([(gt, None, Wp[:, F:5 * F]), (gt, amp, Wp[:, 5 * F:9 * F]), (gt, att, Wp[:, 9 * F:13 * F])],
+                     dA[:, t * 4 * F:(t + 1) * 4 * F], b_trans=False)
+        ge = ops.pna_aggregate_bwd(dA, hs[-1], A, pack, T, F)
+        for i in range(pre_layers - 1, 0, -1):
+            h_prev = hs[i - 1]
+            gn = _empty(E, H, x)
+            for t in range(T):
+                k = pidx(t, "pre", i)
+                ops.gemm_wgrad(ge[:, sl[t]], h_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
+                ops.gemm([(ge[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=h_prev[:, sl[t]])
+            ge = gn
+        dP, dQ, dTe = ops.edge_combine_bwd(ge, pack, R)
+        dEE = _empty(R, F, x)
+        dx = _empty(N, H, x)
+        for t in range(T):
+            k0 = pidx(t, "pre", 0)
+            W0, dW0 = params[k0], grads[k0]
+            kp = pidx(t, "post", 0)
+            xt = x[:, sl[t]]
+            ops.gemm_wgrad(dP[:, sl[t]], xt, dW0[:, 0:F])
+            ops.gemm_wgrad(dQ[:, sl[t]], xt, dW0[:, F:2 * F])
+            ops.gemm_wgrad(dTe[:, sl[t]], EE, dW0[:, 2 * F:3 * F], dbias=grads[k0 + 1])
+            ops.gemm([(dTe[:, sl[t]], None, W0[:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
+            ops.gemm([(g[:, sl[t]], None, params[kp][:, 0:F]), (dP[:, sl[t]], None, W0[:, 0:F]),
+                      (dQ[:, sl[t]], None, W0[:, F:2 * F])], dx[:, sl[t]], b_trans=False)
+        ops.gemm_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
+        dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
+        return (dx, dBE, None, None, *grads)
+
+
+class GINEConvFn(torch.autograd.Function):
+    """[3P] torch_geometric.nn.GINEConv(nn=Seq(Linear, ReLU, Linear), eps=0, train_eps=False, edge_dim=H) as built at
+    models.py:529-538.  lin(edge_attr) is evaluated on the 60-row bond table; message, ReLU and
+    sum-aggregation are one gather kernel (no [E,H] message tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, BE, pack: GraphPack, eps, lin_w, lin_b, w0, b0, w2, b2):
+        x = x.contiguous()
+        N, H = x.shape
+        R = BE.size(0)
+        Le = ops.gemm([(BE, None, lin_w)], _empty(R, lin_w.size(0), x), bias=lin_b)
+        agg = ops.gine_aggregate_fwd(x, Le, pack, eps)
+        a1 = ops.gemm([(agg, None, w0)], _empty(N, w0.size(0), x), bias=b0, relu=True)
+        out = ops.gemm([(a1, None, w2)], _empty(N, w2.size(0), x), bias=b2)
+        ctx.pack, ctx.eps = pack, eps
+        ctx.save_for_backward(x, BE, Le, agg, a1, lin_w, w0, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, BE, Le, agg, a1, lin_w, w0, w2 = ctx.saved_tensors
+        pack: GraphPack = ctx.pack
+        dout = dout.contiguous()
+        N, H = x.shape
+        dev = dict(dtype=torch.float32, device=x.device)
+        dw2, db2 = _zeros_like(w2), torch.zeros(w2.size(0), **dev)
+        dw0, db0 = _zeros_like(w0), torch.zeros(w0.size(0), **dev)
+        dlw, dlb = _zeros_like(lin_w), torch.zeros(lin_w.size(0), **dev)
+        ops.gemm_wgrad(dout, a1, dw2, dbias=db2)
+        g1 = ops.gemm([(dout, None, w2)], _empty(N, a1.size(1), x), b_trans=False, mask=a1)
+        ops.gemm_wgrad(g1, agg, dw0, dbias=db0)
+        dagg = ops.gemm([(g1, None, w0)], _empty(N, H, x), b_trans=False)
+        dx, dLe = ops.gine_aggregate_bwd(dagg, x, Le, pack, ctx.eps)
+        ops.gemm_wgrad(dLe, BE, dlw, dbias=dlb)
+        dBE = ops.gemm([(dLe, None, lin_w)], _empty(BE.size(0), BE.size(1), x), b_trans=False)
+        return dx, dBE, None, None, dlw, dlb, dw0, db0, dw2, db2

@@ -1,0 +1,341 @@
+"""Tensor-level wrappers over the C ABI (include/gnx.h): torch tensors in, ``data_ptr()`` + sizes across ctypes.
+
+torch is used for device memory and streams only; every arithmetic op on the hot path is a gnx kernel.  All wrappers
+require HIP-device fp32 / int64 / int32 tensors and raise ``GnxError`` otherwise — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmSeg, check, handle
+
+_I32 = C.c_int32
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def _mat(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    """(data_ptr, leading dimension) of a 2-D fp32 view whose rows are contiguous."""
+    _f32(t, name)
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"{name}: need a 2-D view with unit column stride, got "
+                                                f"shape {tuple(t.shape)} strides {t.stride()}")
+    ld = t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+    return t.data_ptr(), max(ld, t.size(1))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _carr(vals: Sequence[int]):
+    return (_I32 * len(vals))(*vals)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# packer
+# ------------------------------------------------------------------------------------------------------------------
+class GraphPack:
+    """Device-resident integer structure of one batch: dst-sorted CSR + by-source index + bond codes + graph_ptr.
+
+    Everything the kernels need in place of ``edge_index`` / ``batch``.  int32 throughout.
+    """
+
+    __slots__ = ("N", "E", "B", "rowptr", "perm", "src", "dst", "colptr", "cpos", "code", "graph_ptr", "device",
+                 "_scalers", "has_batch")
+
+    def degree_scalers(self, avg_deg_log: float) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = float(avg_deg_log)
+        hit = self._scalers.get(key)
+        if hit is None:
+            amp = torch.empty(self.N, dtype=torch.float32, device=self.device)
+            att = torch.empty(self.N, dtype=torch.float32, device=self.device)
+            check(_lib.load().gnx_degree_scalers(handle(self.device), self.rowptr.data_ptr(), self.N, key,
+                                                 amp.data_ptr(), att.data_ptr()))
+            hit = (amp, att)
+            self._scalers[key] = hit
+        return hit
+
+
+def check_range(device: torch.device) -> None:
+    """Synchronise and raise ``GnxError(GNX_E_RANGE)`` if any packer / embedding kernel saw an out-of-range integer."""
+    check(_lib.load().gnx_check_range(handle(device)))
+
+
+def pack_graph(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], batch: Optional[torch.Tensor],
+               num_nodes: int, num_graphs: Optional[int] = None, bond_dims: Sequence[int] = (5, 6, 2),
+               validate: bool = True) -> GraphPack:
+    """edge_index int64[2,E], edge_attr int64[E,K], batch int64[N]|None  ->  GraphPack (all on edge_index.device)."""
+    dev = edge_index.device
+    lib, h = _lib.load(), handle(dev)
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"edge_index must be int64[2,E], got {edge_index.dtype} "
+                                                f"{tuple(edge_index.shape)}")
+    edge_index = edge_index.contiguous()
+    N, E = int(num_nodes), int(edge_index.size(1))
+    i32 = dict(dtype=torch.int32, device=dev)
+    g = GraphPack()
+    g.N, g.E, g.device, g._scalers = N, E, dev, {}
+    g.rowptr = torch.empty(N + 1, **i32)
+    g.colptr = torch.empty(N + 1, **i32)
+    g.perm = torch.empty(E, **i32)
+    g.src = torch.empty(E, **i32)
+    g.dst = torch.empty(E, **i32)
+    g.cpos = torch.empty(E, **i32)
+    ws_bytes = lib.gnx_pack_csr_workspace_bytes(N, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.gnx_pack_csr(h, edge_index.data_ptr(), E, N, g.rowptr.data_ptr(), g.perm.data_ptr(), g.src.data_ptr(),
+                           g.dst.data_ptr(), g.colptr.data_ptr(), g.cpos.data_ptr(), ws.data_ptr(), ws_bytes))
+    g.code = torch.empty(E, **i32)
+    if edge_attr is not None:
+        if edge_attr.dtype != torch.int64 or edge_attr.dim() != 2 or edge_attr.size(0) != E or \
+                edge_attr.size(1) != len(bond_dims):
+            raise _lib.GnxError(_lib.GNX_E_INVALID, f"edge_attr must be int64[E,{len(bond_dims)}], got "
+                                                    f"{edge_attr.dtype} {tuple(edge_attr.shape)}")
+        edge_attr = edge_attr.contiguous()
+        check(lib.gnx_feature_code(h, edge_attr.data_ptr(), E, len(bond_dims), _carr(list(bond_dims)),
+                                   g.perm.data_ptr(), g.code.data_ptr(), None, 0))
+    else:
+        g.code.zero_()
+    if batch is not None:
+        if batch.dtype != torch.int64 or batch.dim() != 1 or batch.size(0) != N:
+            raise _lib.GnxError(_lib.GNX_E_INVALID, f"batch must be int64[N], got {batch.dtype} {tuple(batch.shape)}")
+        if num_graphs is None:
+            # PyG: dim_size = batch.max() + 1 (device sync); pass num_graphs to avoid it
+            num_graphs = int(batch.max()) + 1 if N > 0 else 0
+        g.B = int(num_graphs)
+        g.has_batch = True
+        g.graph_ptr = torch.empty(g.B + 1, **i32)
+        check(lib.gnx_graph_ptr(h, batch.contiguous().data_ptr(), N, g.B, g.graph_ptr.data_ptr(), None, 0))
+    else:
+        g.B = 1
+        g.has_batch = False
+        g.graph_ptr = torch.tensor([0, N], **i32)
+    if validate:
+        check_range(dev)
+    return g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# embeddings
+# ------------------------------------------------------------------------------------------------------------------
+def embed_sum_fwd(idx: torch.Tensor, table: torch.Tensor, offsets: Sequence[int]) -> torch.Tensor:
+    K = len(offsets) - 1
+    if idx.dtype != torch.int64 or idx.dim() != 2 or idx.size(1) != K:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"embedding index must be int64[N,{K}], got {idx.dtype} "
+                                                f"{tuple(idx.shape)}")
+    idx = idx.contiguous()
+    table = _f32(table, "table").contiguous()
+    N, H = idx.size(0), table.size(1)
+    out = torch.empty(N, H, dtype=torch.float32, device=table.device)
+    check(_lib.load().gnx_embed_sum_fwd(handle(table.device), idx.data_ptr(), N, K, _carr(list(offsets)),
+                                        table.data_ptr(), H, out.data_ptr()))
+    return out
+
+
+def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor) -> torch.Tensor:
+    K, R = len(offsets) - 1, offsets[-1]
+    dout = _f32(dout, "dout").contiguous()
+    idx = idx.contiguous()
+    H = dout.size(1)
+    dtable = torch.zeros(R, H, dtype=torch.float32, device=dout.device)
+    check(_lib.load().gnx_embed_sum_bwd(handle(dout.device), idx.data_ptr(), idx.size(0), K, _carr(list(offsets)), R,
+                                        dout.data_ptr(), H, dtable.data_ptr()))
+    return dtable
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dense
+# ------------------------------------------------------------------------------------------------------------------
+Seg = Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]  # (A view [M,k], rowscale [M] | None, B view)
+
+
+def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+         mask: Optional[torch.Tensor] = None, relu: bool = False, accumulate: bool = False,
+         b_trans: bool = True) -> torch.Tensor:
+    """out[M,N] (+)= act(sum_s (rs_s * A_s) @ B_s(^T) + bias), optionally * (mask > 0).  See gnx_gemm in gnx.h.
+
+    b_trans=True: B_s is a [N,k] weight view (forward Linear); False: B_s is a [k,N] view (input gradient).
+    """
+    M, N = out.shape
+    if M == 0:
+        return out
+    cptr, ldc = _mat(out, "out")
+    arr = (GemmSeg * len(segs))()
+    for i, (a, rs, b) in enumerate(segs):
+        ap, lda = _mat(a, f"A[{i}]")
+        bp, ldb = _mat(b, f"B[{i}]")
+        k = a.size(1)
+        if a.size(0) != M or (b_trans and (b.size(0) != N or b.size(1) != k)) or \
+                (not b_trans and (b.size(0) != k or b.size(1) != N)):
+            raise _lib.GnxError(_lib.GNX_E_INVALID, f"gemm segment {i}: A {tuple(a.shape)} B {tuple(b.shape)} "
+                                                    f"out {tuple(out.shape)} b_trans={b_trans}")
+        arr[i].a, arr[i].lda, arr[i].rowscale = ap, lda, _ptr(rs)
+        arr[i].b, arr[i].ldb, arr[i].k = bp, ldb, k
+    flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0) | \
+            (_lib.GEMM_B_TRANS if b_trans else 0)
+    mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
+    check(_lib.load().gnx_gemm(handle(out.device), len(segs), arr, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags))
+    return out
+
+
+def gemm_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale: Optional[torch.Tensor] = None,
+               dbias: Optional[torch.Tensor] = None) -> None:
+    """dW[N,K] += dC[M,N]^T @ (rowscale * A[M,K]);  dbias[N] += column sums of dC."""
+    M, N = dC.shape
+    if M == 0:
+        return
+    xp, ldx = _mat(dC, "dC")
+    ap, lda = _mat(A, "A")
+    wp, ldw = _mat(dW, "dW")
+    K = A.size(1)
+    if A.size(0) != M or dW.size(0) != N or dW.size(1) != K:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"wgrad shapes dC {tuple(dC.shape)} A {tuple(A.shape)} "
+                                                f"dW {tuple(dW.shape)}")
+    check(_lib.load().gnx_gemm_wgrad(handle(dW.device), xp, ldx, ap, lda, _ptr(rowscale), M, N, K, wp, ldw,
+                                     _ptr(dbias)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# message passing
+# ------------------------------------------------------------------------------------------------------------------
+def edge_combine_fwd(P: torch.Tensor, Q: torch.Tensor, Te: torch.Tensor, g: GraphPack, relu: bool) -> torch.Tensor:
+    H = P.size(1)
+    h1 = torch.empty(g.E, H, dtype=torch.float32, device=P.device)
+    check(_lib.load().gnx_edge_combine_fwd(handle(P.device), P.data_ptr(), Q.data_ptr(), Te.data_ptr(),
+                                           g.src.data_ptr(), g.dst.data_ptr(), g.code.data_ptr(), g.E, H, int(relu),
+                                           h1.data_ptr()))
+    return h1
+
+
+def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    H = gr.size(1)
+    dP = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
+    dQ = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
+    dTe = torch.zeros(R, H, dtype=torch.float32, device=gr.device)
+    check(_lib.load().gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
+                                           g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(),
+                                           dQ.data_ptr(), dTe.data_ptr()))
+    return dP, dQ, dTe
+
+
+def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:
+    A = torch.empty(g.N, T * 4 * F, dtype=torch.float32, device=m.device)
+    check(_lib.load().gnx_pna_aggregate_fwd(handle(m.device), m.data_ptr(), g.rowptr.data_ptr(), g.N, T, F,
+                                            A.data_ptr()))
+    return A
+
+
+def pna_aggregate_bwd(dA: torch.Tensor, m: torch.Tensor, A: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:
+    dm = torch.empty_like(m)
+    check(_lib.load().gnx_pna_aggregate_bwd(handle(m.device), dA.data_ptr(), m.data_ptr(), A.data_ptr(),
+                                            g.rowptr.data_ptr(), g.N, T, F, dm.data_ptr()))
+    return dm
+
+
+def gine_aggregate_fwd(x: torch.Tensor, Le: torch.Tensor, g: GraphPack, eps: float) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(_lib.load().gnx_gine_aggregate_fwd(handle(x.device), x.data_ptr(), Le.data_ptr(), g.rowptr.data_ptr(),
+                                             g.src.data_ptr(), g.code.data_ptr(), g.N, x.size(1), float(eps),
+                                             out.data_ptr()))
+    return out
+
+
+def gine_aggregate_bwd(dout: torch.Tensor, x: torch.Tensor, Le: torch.Tensor, g: GraphPack,
+                       eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    dx = torch.empty_like(x)
+    dLe = torch.zeros_like(Le)
+    check(_lib.load().gnx_gine_aggregate_bwd(handle(x.device), dout.data_ptr(), x.data_ptr(), Le.data_ptr(),
+                                             g.colptr.data_ptr(), g.cpos.data_ptr(), g.src.data_ptr(),
+                                             g.dst.data_ptr(), g.code.data_ptr(), g.N, g.E, x.size(1), Le.size(0),
+                                             float(eps), dx.data_ptr(), dLe.data_ptr()))
+    return dx, dLe
+
+
+_POOL = {"add": _lib.POOL_ADD, "sum": _lib.POOL_ADD, "mean": _lib.POOL_MEAN, "max": _lib.POOL_MAX}
+
+
+def segment_pool_fwd(x: torch.Tensor, ptr: torch.Tensor, B: int, mode: str) -> torch.Tensor:
+    out = torch.empty(B, x.size(1), dtype=torch.float32, device=x.device)
+    check(_lib.load().gnx_segment_pool_fwd(handle(x.device), x.data_ptr(), ptr.data_ptr(), B, x.size(1), _POOL[mode],
+                                           out.data_ptr()))
+    return out
+
+
+def segment_pool_bwd(dout: torch.Tensor, x: torch.Tensor, out: torch.Tensor, ptr: torch.Tensor, B: int,
+                     mode: str) -> torch.Tensor:
+    dx = torch.empty_like(x)
+    check(_lib.load().gnx_segment_pool_bwd(handle(x.device), dout.data_ptr(), x.data_ptr(), out.data_ptr(),
+                                           ptr.data_ptr(), B, x.size(1), _POOL[mode], dx.data_ptr()))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# normalisation / loss
+# ------------------------------------------------------------------------------------------------------------------
+def _bn_ws(M: int, H: int, dev) -> Tuple[torch.Tensor, int]:
+    nbytes = _lib.load().gnx_batchnorm_workspace_bytes(M, H)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum: float, eps: float, training: bool, relu: bool):
+    M, H = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(H, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(H, dtype=torch.float32, device=x.device)
+    ws, nbytes = _bn_ws(M, H, x.device)
+    check(_lib.load().gnx_batchnorm_fwd(handle(x.device), x.data_ptr(), M, H, _ptr(gamma), _ptr(beta),
+                                        _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                        int(training), int(relu), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        ws.data_ptr(), nbytes))
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu: bool):
+    M, H = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.zeros(H, dtype=torch.float32, device=x.device)
+    dbeta = torch.zeros(H, dtype=torch.float32, device=x.device)
+    ws, nbytes = _bn_ws(M, H, x.device)
+    check(_lib.load().gnx_batchnorm_bwd(handle(x.device), dy.data_ptr(), x.data_ptr(), y.data_ptr(), M, H, _ptr(gamma),
+                                        mean.data_ptr(), rstd.data_ptr(), int(relu), dx.data_ptr(), dgamma.data_ptr(),
+                                        dbeta.data_ptr(), ws.data_ptr(), nbytes))
+    return dx, dgamma, dbeta
+
+
+def huber_ape(pred: torch.Tensor, target: torch.Tensor, delta: float, need_grad: bool):
+    pred = _f32(pred, "pred").contiguous()
+    target = _f32(target, "target").contiguous()
+    if pred.shape != target.shape:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+    out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if need_grad else None
+    check(_lib.load().gnx_huber_ape(handle(pred.device), pred.data_ptr(), target.data_ptr(), pred.numel(), float(delta),
+                                    out2.data_ptr(), _ptr(dpred)))
+    return out2, dpred
+
+
+def clip_rows(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    x = _f32(x, "x").contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().gnx_clip_rows(handle(x.device), x.data_ptr(), x.size(0), x.size(1), lo.data_ptr(), hi.data_ptr(),
+                                    y.data_ptr()))
+    return y
+
+
+def prof_begin(device: torch.device, kernel_id: int) -> None:
+    check(_lib.load().gnx_prof_begin(handle(device), kernel_id))
+
+
+def prof_end(device: torch.device) -> Tuple[int, float]:
+    n, ms = C.c_int64(0), C.c_double(0.0)
+    check(_lib.load().gnx_prof_end(handle(device), C.byref(n), C.byref(ms)))
+    return n.value, ms.value

@@ -1,0 +1,204 @@
+/*
+ * gnx.h — C ABI of libgnnepcsaft_hip.so: the MI355X (gfx950) kernels behind gnnepcsaft's GNN forward/backward.
+ *
+ * The reference has no FFI for this path: the arithmetic sits in torch_geometric / ogb Python modules that
+ * /root/reference/gnnepcsaft/train/models.py only wires together.  Each entry point below therefore cites the
+ * reference call site (ref: = /root/reference/gnnepcsaft/...) and the third-party op [3P] it stands in for.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch types.
+ *  - every function returns int32 status: 0 = ok, <0 = error (GNX_E_*); text via gnx_last_error() (thread-local).
+ *  - the library never allocates or frees tensor memory: all buffers (inputs, outputs, workspaces) are caller-owned
+ *    DEVICE pointers (hipMalloc / torch tensors' data_ptr()); workspace sizes are queried with *_workspace_bytes.
+ *  - all launches go on the handle's stream (gnx_set_stream; default = the NULL stream) and are asynchronous.
+ *    Only gnx_check_range (integer input validation read-back) and gnx_prof_end synchronise that stream.
+ *  - all float tensors are fp32 row-major; "ld" = leading dimension in elements.  Index tensors handed over by the
+ *    caller in the reference's layout are int64; everything the library produces is int32.
+ *  - no hidden global state except the opaque gnx_handle (device id, stream, profiling events).
+ */
+#ifndef GNX_H_
+#define GNX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNX_ABI_VERSION 1
+
+enum {
+  GNX_OK = 0,
+  GNX_E_INVALID = -1,   /* bad argument (shape, alignment, null pointer) */
+  GNX_E_HIP = -2,       /* HIP runtime error; see gnx_last_error() */
+  GNX_E_RANGE = -3,     /* integer input out of range (node id >= N, feature >= vocab, unsorted batch) */
+  GNX_E_WORKSPACE = -4  /* workspace too small */
+};
+
+typedef struct gnx_handle gnx_handle;
+
+/* ---- lifecycle --------------------------------------------------------------------------------------------- */
+int32_t gnx_create(gnx_handle** out, int32_t device);
+int32_t gnx_destroy(gnx_handle* h);
+int32_t gnx_set_stream(gnx_handle* h, void* hip_stream);
+const char* gnx_last_error(void);
+int32_t gnx_abi_version(void);
+
+/* ---- profiling hook (bench.py's live per-kernel timing; HIP events on the handle's stream) ------------------- */
+/* kernel ids */
+enum {
+  GNX_K_NONE = 0,
+  GNX_K_PNA_AGG_FWD = 1,
+  GNX_K_PNA_AGG_BWD = 2,
+  GNX_K_GEMM = 3,
+  GNX_K_GEMM_WGRAD = 4,
+  GNX_K_GINE_AGG_FWD = 5,
+  GNX_K_GINE_AGG_BWD = 6,
+  GNX_K_EDGE_COMBINE_FWD = 7,
+  GNX_K_EDGE_COMBINE_BWD = 8,
+  GNX_K_BN_FWD = 9,
+  GNX_K_BN_BWD = 10,
+  GNX_K_COUNT = 11
+};
+/* start recording an event pair around every launch of kernel `kid` (GNX_K_NONE disables). */
+int32_t gnx_prof_begin(gnx_handle* h, int32_t kid);
+/* synchronise the stream, return #launches seen and their summed duration in milliseconds, and stop recording. */
+int32_t gnx_prof_end(gnx_handle* h, int64_t* launches, double* total_ms);
+
+/* ---- input packer: PyG-style COO batch -> dst-sorted CSR (+ by-source index) ------------------------------- */
+/* Replaces what PNAConv/GINEConv's MessagePassing.propagate [3P] does implicitly with edge_index on every call
+ * (ref: train/models.py:212-214), and utils.degree [3P] (ref: train/models.py:445-457 via DegreeScalerAggregation).
+ *   edge_index int64[2,E] (row 0 = source j, row 1 = target i), N nodes.
+ *   rowptr  int32[N+1]  CSR by target;  perm int32[E]: CSR position p -> original edge id, STABLE (ascending inside a
+ *   row, i.e. the order scatter_add_ visits them);  src int32[E], dst int32[E]: endpoints in CSR order;
+ *   colptr int32[N+1], cpos int32[E]: for every source node the ascending list of CSR positions leaving it.
+ * Bit-exact integer work.  Out-of-range node ids are clamped and set the handle's sticky range flag (bit 0), which
+ * gnx_check_range reports (the only synchronising call), so a training loop can validate once per step. */
+size_t gnx_pack_csr_workspace_bytes(int64_t N, int64_t E);
+int32_t gnx_pack_csr(gnx_handle* h, const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* perm,
+                     int32_t* src, int32_t* dst, int32_t* colptr, int32_t* cpos, void* ws, size_t ws_bytes);
+/* mixed-radix code of the K integer features of every row, gathered through perm (perm may be NULL = identity):
+ *   code[p] = ((f[perm[p],0]*dims[1] + f[perm[p],1])*dims[2] + ...) ; dims is a HOST array of K vocab sizes.
+ * Used for edge_attr int64[E,3] -> bond code in [0,60) (vocab ref: data/ogb_utils.py:24-33). Range-checked lazily (sticky flag bit 1).
+ * ws: unused (may be NULL). */
+int32_t gnx_feature_code(gnx_handle* h, const int64_t* feat, int64_t rows, int32_t K, const int32_t* dims,
+                         const int32_t* perm, int32_t* code, void* ws, size_t ws_bytes);
+/* batch int64[N] (non-decreasing graph id per node, PyG Batch.batch) -> graph_ptr int32[B+1]. Range/sortedness
+ * checked lazily (sticky flag bits 2/3). ws: unused (may be NULL). */
+int32_t gnx_graph_ptr(gnx_handle* h, const int64_t* batch, int64_t N, int64_t B, int32_t* graph_ptr, void* ws,
+                      size_t ws_bytes);
+/* PNA degree scalers [3P DegreeScalerAggregation]: amp[n] = log(d+1)/avg_deg_log, att[n] = avg_deg_log/log(max(d,1)+1),
+ * d = rowptr[n+1]-rowptr[n]. */
+int32_t gnx_degree_scalers(gnx_handle* h, const int32_t* rowptr, int64_t N, float avg_deg_log, float* amp, float* att);
+
+/* ---- embeddings: AtomEncoder / BondEncoder [3P ogb] (ref: train/models.py:175-176, 205-206) ----------------- */
+/* out[n,:] = sum_{k<K} table[offsets[k] + idx[n,k], :], summed left to right in fp32 (bit-exact with the CPU path).
+ * idx int64[N,K]; table fp32[R,H] = the K embedding tables stacked; offsets: HOST int32[K+1] (row offsets, last = R).
+ * Range-checked lazily: an out-of-range index poisons nothing (it is clamped) and sets the handle's sticky range
+ * flag, reported by the next gnx_pack_* / gnx_check_range call. */
+int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
+                          const float* table, int32_t H, float* out);
+/* dtable[R,H] += scatter-add of dout[N,H] (embedding_dense_backward); LDS-privatised, then one atomic per row/col. */
+int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
+                          int32_t R, const float* dout, int32_t H, float* dtable);
+int32_t gnx_check_range(gnx_handle* h); /* sync; GNX_E_RANGE if any lazy check tripped since the last call */
+
+/* ---- dense contractions: fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 ------------------------------------ */
+/* One A-operand segment of a K-concatenated product.  The product is
+ *     C[m,n] (+)= act( sum_s  sum_{k<K_s} (rs_s[m] * A_s[m,k]) * B_s(k,n)  + bias[n] )        m<M, n<N
+ *   b_trans = 1 ("NT", forward Linear):   B_s(k,n) = B_s[n*ldb + k]   (weight [out,in] row-major, PyG/torch layout)
+ *   b_trans = 0 ("NN", input gradient):   B_s(k,n) = B_s[k*ldb + n]
+ * rowscale may be NULL (=1).  Segments let the caller feed torch.cat([...], dim=-1) operands without materialising
+ * them: PNAConv's [x_i || x_j || e] pre-layer and the 13F-wide [x || A || amp*A || att*A] post-layer
+ * ([3P] PNAConv.message / DegreeScalerAggregation; ref: train/models.py:445-457). */
+typedef struct {
+  const float* a;        /* [M, k] with leading dimension lda */
+  int64_t lda;
+  const float* rowscale; /* [M] or NULL */
+  const float* b;        /* segment's slice of the weight */
+  int64_t ldb;
+  int32_t k;
+  int32_t _pad;
+} gnx_gemm_seg;
+
+enum {
+  GNX_GEMM_RELU = 1,       /* C = max(.,0) */
+  GNX_GEMM_ACCUMULATE = 2, /* C += (applied before relu; relu+accumulate is rejected) */
+  GNX_GEMM_B_TRANS = 4     /* NT */
+};
+/* mask (optional, may be NULL): multiply the result by (mask[m*ldmask+n] > 0) — ReLU backward fused in dgrad. */
+int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N, const float* bias,
+                 const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags);
+/* weight gradient ("TN"): dW[n, k] += sum_m dC[m,n] * (rs[m] * A[m,k]),  n<N, k<K.  Split over M across workgroups,
+ * fp32 atomics into dW (caller zeroes or accumulates).  dbias (optional) += column sums of dC. */
+int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
+                       const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias);
+
+/* ---- PNA message assembly (first pre-layer folded to node level) ------------------------------------------- */
+/* h1[p,:] = relu(P[dst[p],:] + Q[src[p],:] + Te[code[p],:])  for CSR position p;  width = H.
+ * ([3P] PNAConv.message: Linear(3F->F) on cat([x_i, x_j, e]) == W_i x_i + W_j x_j + (W_e e + b), then ReLU.) */
+int32_t gnx_edge_combine_fwd(gnx_handle* h, const float* P, const float* Q, const float* Te, const int32_t* src,
+                             const int32_t* dst, const int32_t* code, int64_t E, int32_t H, int32_t relu, float* h1);
+/* given g[E,H] (already masked by relu'):  dP[i,:] = sum_{p in row i} g[p,:] ;  dQ[j,:] = sum_{p in cpos(j)} g[p,:] ;
+ * dTe[R,H] += scatter-add by code (LDS-privatised). dP/dQ are overwritten. */
+int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int32_t* rowptr, const int32_t* colptr,
+                             const int32_t* cpos, const int32_t* code, int64_t N, int64_t E, int32_t H, int32_t R,
+                             float* dP, float* dQ, float* dTe);
+
+/* ---- the scatter-aggregate: PNA mean|min|max|std over target nodes  (HBM-bound; the roofline kernel) ------- */
+/* [3P] MultiAggregation([Mean,Min,Max,Std], mode='cat') as used by DegreeScalerAggregation
+ * (aggregator list ref: train/models.py:443).  m fp32[E, T*F] in CSR order, rowptr int32[N+1].
+ * A fp32[N, T, 4F]: per tower [mean || min || max || std].  Empty rows -> 0.  mean = (sequential sum in CSR order)/max(d,1);
+ * std = sqrt(max(mean(x*x) - mean^2, 1e-5)) masked to 0 when <= sqrt(1e-5). */
+int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int32_t T, int32_t F,
+                              float* A);
+/* dm[E,T*F] from dA[N,T,4F]; min/max gradients split evenly over ties (scatter_reduce amin/amax backward);
+ * std gradient 0 where the forward masked. */
+int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A, const int32_t* rowptr,
+                              int64_t N, int32_t T, int32_t F, float* dm);
+
+/* ---- GINE message + sum aggregate (fused gather, no materialised messages) --------------------------------- */
+/* [3P] GINEConv (ref: train/models.py:529-538): out[i,:] = (1+eps) x[i,:] + sum_{p in row i} relu(x[src[p],:] + Le[code[p],:]) */
+int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const float* Le, const int32_t* rowptr,
+                               const int32_t* src, const int32_t* code, int64_t N, int32_t H, float eps, float* out);
+/* dx[j,:] = (1+eps) dout[j,:] + sum_{p in cpos(j)} dout[dst[p],:] * (x[j,:] + Le[code[p],:] > 0);
+ * dLe[R,H] (optional) += sum_p [code[p]==r] dout[dst[p],:] * (x[src[p],:] + Le[r,:] > 0), LDS-privatised. */
+int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, const float* x, const float* Le,
+                               const int32_t* colptr, const int32_t* cpos, const int32_t* src, const int32_t* dst,
+                               const int32_t* code, int64_t N, int64_t E, int32_t H, int32_t R, float eps, float* dx,
+                               float* dLe);
+
+/* ---- contiguous segment reduce: global pool (ref: train/models.py:218-225, 587-595) ------------------------ */
+enum { GNX_POOL_ADD = 0, GNX_POOL_MEAN = 1, GNX_POOL_MAX = 2 };
+int32_t gnx_segment_pool_fwd(gnx_handle* h, const float* x, const int32_t* ptr, int64_t B, int32_t H, int32_t mode,
+                             float* out);
+int32_t gnx_segment_pool_bwd(gnx_handle* h, const float* dout, const float* x, const float* out, const int32_t* ptr,
+                             int64_t B, int32_t H, int32_t mode, float* dx);
+
+/* ---- BatchNorm1d (+ReLU) over rows (ref: train/models.py:184,212-214 and the readout mlp :186-194) ---------- */
+size_t gnx_batchnorm_workspace_bytes(int64_t M, int32_t H);
+/* training: batch statistics (biased var to normalise, unbiased into running_var, momentum), saves mean/rstd[H].
+ * eval (training=0): uses running stats. y = relu?(gamma*(x-mean)*rstd + beta). */
+int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, int32_t H, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                          int32_t relu, float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes);
+/* dy masked by (y>0) when relu; dgamma/dbeta are ACCUMULATED (+=). */
+int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float* x, const float* y, int64_t M, int32_t H,
+                          const float* gamma, const float* save_mean, const float* save_rstd, int32_t relu,
+                          float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes);
+
+/* ---- loss: APE-Huber (ref: train/models.py:89-91) + MAPE metric (:92) ---------------------------------------- */
+/* out[0] = mean huber((pred-t)/t, delta), out[1] = mean |pred-t|/max(|t|,1.17e-6); dpred (optional) = d out[0]/d pred. */
+int32_t gnx_huber_ape(gnx_handle* h, const float* pred, const float* target, int64_t count, float delta, float* out2,
+                      float* dpred);
+
+/* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
+int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
+/* y[m,:] = clip(x[m,:], lo[:], hi[:])   (pred_with_bounds, ref: train/models.py:246-253) */
+int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo, const float* hi, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNX_H_ */
