@@ -165,11 +165,14 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
   vload<VEC>(gmn, dA + ao + F);
   vload<VEC>(gmx, dA + ao + 2 * F);
   vload<VEC>(gsd, dA + ao + 3 * F);
+  // torch's scatter_reduce(amin/amax) backward divides by (#src ties + [self == result]) with self = the zero-filled
+  // output buffer, also under include_self=False: an extremum that is exactly 0 counts one extra tie.  The reference's
+  // CPU path behaves that way (verified on torch 2.10: src [0,-1,0] -> grads [1/3,0,1/3]); reproduced here.
   float nmn[VEC], nmx[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    nmn[v] = 0.f;
-    nmx[v] = 0.f;
+    nmn[v] = (mn[v] == 0.f) ? 1.f : 0.f;
+    nmx[v] = (mx[v] == 0.f) ? 1.f : 0.f;
   }
   const float* mp = m + (int64_t)p0 * H + c;
   for (int p = p0; p < p1; ++p, mp += H) {
@@ -518,7 +521,7 @@ __global__ void __launch_bounds__(256) k_pool_bwd(const float* __restrict__ dout
     float mx[VEC], nt[VEC];
     vload<VEC>(mx, out + b * H + c);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) nt[v] = 0.f;
+    for (int v = 0; v < VEC; ++v) nt[v] = (mx[v] == 0.f) ? 1.f : 0.f;  // zero-filled self counts as a tie (see PNA bwd)
     for (int p = p0; p < p1; ++p) {
       float a[VEC];
       vload<VEC>(a, x + (int64_t)p * H + c);

@@ -279,6 +279,11 @@ def test_pna_known_answers(gpu_device):
     dA[:, 8:12] = 1.0  # d/dmax
     dm = ops.pna_aggregate_bwd(dA.to(gpu_device), m.to(gpu_device), A.reshape(4, 16).to(gpu_device), g, 1, 4).cpu()
     assert torch.equal(dm[:, 0], torch.tensor([0.5, 0.5, 0.0, 0.0, 1.0]))
+    # torch quirk reproduced: an extremum equal to 0 (the zero-filled scatter target) counts one extra tie
+    m0 = torch.tensor([[0.0], [-1.0], [0.0], [2.0], [2.0]]).repeat(1, 4)
+    A0 = ops.pna_aggregate_fwd(m0.to(gpu_device), g, 1, 4)
+    dm0 = ops.pna_aggregate_bwd(dA.to(gpu_device), m0.to(gpu_device), A0, g, 1, 4).cpu()
+    assert torch.allclose(dm0[:, 0], torch.tensor([1 / 3, 0.0, 1 / 3, 0.5, 0.5]), rtol=1e-6, atol=0)
     # std: var in {0, 1e-6, 1e-5} -> 0 ; var = 2e-5 -> 4.4721e-3
     for var, want in [(0.0, 0.0), (1e-6, 0.0), (2e-5, 4.4721e-3)]:
         s = math.sqrt(var)
@@ -381,7 +386,8 @@ def test_batchnorm_train(gpu_device, M, H, relu):
     d = torch.randn(M, H)
     yo.backward(d)
     yn.backward(d.to(gpu_device))
-    assert rel_err(xn.grad, xo.grad) <= 2e-5
+    # floor: with M=2 rows dx is analytically 0 (noise over noise without it)
+    assert rel_err(xn.grad, xo.grad, floor=1e-3 * float(d.abs().max())) <= 2e-5
     assert rel_err(bn.weight.grad, bo.weight.grad) <= TOL and rel_err(bn.bias.grad, bo.bias.grad) <= TOL
     # eval mode uses running statistics
     bo.eval()
