@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py — graphs/s of the GNN forward+backward hot path on N MI355X (BASELINE.json metric).
+
+One step = zero_grad -> pack (CSR of the resident int64 batch) -> forward -> APE-Huber loss -> backward
+(-> gradient all-reduce when N>1) over one batch of synthetic molecular graphs already resident in HBM
+(optimizer step, data generation and H2D copies excluded).
+
+Workload at N=1: BASELINE.json configs[1] — PNA, hidden=128, L=6, pre=2, post=4, T=1, batch=4096 synthetic molecules of
+20 atoms / 40 directed bonds.  N>1: the same per-GPU batch on every rank (weak scaling), graphs independent per rank,
+one exchange step (flat-buffer gradient all-reduce over RCCL).
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline     — the scatter-aggregate kernel (gnx_pna_aggregate_fwd): algorithmic bytes per launch / its average
+                 duration, timed live with HIP events on the launch stream during the timed steps, vs 8 TB/s HBM;
+  cpu_baseline — the oracle (pure-torch restatement of the reference's PyG CPU path, kind "port") timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def ref_flops_per_graph(cfg, n=20, e=40):
+    """Reference-algorithm dense FLOPs per graph, forward; fwd+bwd = 3x."""
+    H, T, L, P = cfg["hidden_dim"], cfg["towers"], cfg["propagation_depth"], cfg["num_para"]
+    F = H // T
+    if cfg["conv"] == "PNA":
+        f_edge = 2 * H * F + T * (6 * F * F + 2 * (cfg["pre_layers"] - 1) * F * F)
+        f_node = T * (26 * F * F + 2 * (cfg["post_layers"] - 1) * F * F) + 2 * H * H
+    else:
+        f_edge, f_node = 2 * H * H, 4 * H * H
+    f_read = 2 * (H * H // 2 + (H // 2) * (H // 4) + (H // 4) * P)
+    return L * (e * f_edge + n * f_node) + f_read
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (1-5)")
+    ap.add_argument("--batch", type=int, default=0, help="graphs per GPU (default: the config's batch / gpus rule)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback for the product path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gnnepcsaft_amd import _lib, dp, functional as Fn, ops
+    from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
+    from gnnepcsaft_amd.train.models import create_model
+
+    cfg = default_config(args.config)
+    per_gpu = args.batch or {1: 32, 2: 4096, 3: 16384, 4: 131072 // 8, 5: 65536 // 8}[args.config]
+    gen_cfg = 5 if args.config == 5 else args.config
+    # weak scaling: every rank gets its own batch of the same size (different seed), graphs are independent
+    from gnnepcsaft_amd.data.synthetic import BASE_SEED
+    batch_cpu = synthetic_batch(per_gpu, gen_cfg, seed=BASE_SEED + args.config + 1000 * rank)
+    deg = calc_deg(synthetic_batch(min(per_gpu, 4096), gen_cfg))  # same histogram source on every rank
+    torch.manual_seed(0)
+    model = create_model(cfg, deg).to(dev)
+    model.train()
+    model.model.validate_inputs = False  # range flag is read back once per step below (no sync inside the step)
+    dp.broadcast_parameters(model)
+    flat = dp.FlatGradAllReduce(model)
+    b = batch_cpu.to(dev)
+    N_nodes, E_edges = b.x.size(0), b.edge_index.size(1)
+    H, T = cfg["hidden_dim"], cfg["towers"]
+
+    def step():
+        flat.zero_grad()
+        b._gnx_pack = None  # a new batch arrives every step in training: the packer is part of the step
+        loss = model.training_step(b, 0)
+        loss.backward()
+        flat.all_reduce()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    ops.check_range(dev)  # validates the integer inputs of the warm-up steps (sync)
+    torch.cuda.synchronize()
+    agg_k = _lib.K_PNA_AGG_FWD if cfg["conv"] == "PNA" else _lib.K_GINE_AGG_FWD
+    agg_bk = _lib.K_PNA_AGG_BWD if cfg["conv"] == "PNA" else _lib.K_GINE_AGG_BWD
+    ops.prof_begin(dev, [agg_k, agg_bk, _lib.K_GEMM, _lib.K_GEMM_WGRAD])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    ops.check_range(dev)
+    n_f, ms_f = ops.prof_read(dev, agg_k)
+    n_b, ms_b = ops.prof_read(dev, agg_bk)
+    n_g, ms_g = ops.prof_read(dev, _lib.K_GEMM)
+    n_w, ms_w = ops.prof_read(dev, _lib.K_GEMM_WGRAD)
+    ops.prof_end(dev)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+    assert loss_val == loss_val, "loss is NaN"
+
+    if rank == 0:
+        graphs = per_gpu * world * args.steps
+        value = graphs / elapsed
+        # algorithmic bytes of one scatter-aggregate launch: read messages + index, write 4 aggregates
+        if cfg["conv"] == "PNA":
+            alg_f = 4 * E_edges * H + 4 * E_edges + 16 * N_nodes * H
+            alg_b = 16 * N_nodes * H + 8 * E_edges * H + 4 * E_edges
+        else:
+            alg_f = 4 * E_edges * H + 4 * E_edges + 4 * N_nodes * H
+            alg_b = 4 * N_nodes * H + 4 * E_edges + 4 * E_edges * H
+        avg_f = ms_f / max(n_f, 1) * 1e-3
+        achieved = alg_f / avg_f / 1e9 if n_f else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_scatter.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            except Exception:  # pylint: disable=broad-except
+                traffic = None
+        flops = 3 * ref_flops_per_graph(cfg) if args.config != 5 else None
+        out = {
+            "metric": "molecular graphs/sec (fwd+bwd)", "value": value, "unit": "graphs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {cfg['conv']} hidden={H} L={cfg['propagation_depth']} "
+                                   f"towers={T} pre={cfg['pre_layers']} post={cfg['post_layers']}, {per_gpu} graphs/GPU "
+                                   f"({N_nodes} atoms, {E_edges} directed bonds), fwd+loss+bwd incl. CSR packing",
+                       "graphs_per_gpu": per_gpu, "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": flat.nbytes if world > 1 else 0},
+            "loss": loss_val,
+            "roofline": {"bound": "hbm", "kernel": "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "alg_bytes_per_launch": alg_f, "avg_us": avg_f * 1e6, "launches": n_f,
+                         "bwd": {"alg_bytes_per_launch": alg_b, "avg_us": ms_b / max(n_b, 1) * 1e3,
+                                 "achieved": (alg_b / (ms_b / max(n_b, 1) * 1e-3) / 1e9) if n_b else 0.0}},
+            "mfma": {"ref_flops_per_graph_fwd_bwd": flops, "peak_tflops": MFMA_F32_PEAK_TF,
+                     "model_frac_of_f32_mfma_peak": (flops * value / world / 1e12 / MFMA_F32_PEAK_TF) if flops else None,
+                     "gemm_ms_per_step": ms_g / args.steps, "gemm_launches_per_step": n_g / args.steps,
+                     "wgrad_ms_per_step": ms_w / args.steps, "wgrad_launches_per_step": n_w / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, deg, batch_cpu, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, deg, batch_cpu, steps):
+    """The oracle (pure-torch restatement of the reference's PyG CPU op sequence; PyG itself is not installable here)
+    timed on the host cores: zero_grad -> forward -> APE-Huber -> backward, same batch, fp32, all cores."""
+    import copy
+    from oracle import pyg_restatement as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    c = copy.deepcopy(cfg)
+    c["deg"] = deg
+    torch.manual_seed(0)
+    model = O.GNNePCSAFT(c)
+    model.train()
+    B = int(batch_cpu.num_graphs)
+    times = []
+    budget_t0 = time.perf_counter()
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        model.zero_grad()
+        pred = model(batch_cpu.x, batch_cpu.edge_index, batch_cpu.edge_attr, batch_cpu.batch)
+        loss = O.ape_huber_loss(pred, batch_cpu.para)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+        if time.perf_counter() - budget_t0 > 60 and times:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed fwd+bwd steps (1 warm-up) of the same {B}-graph batch, median; oracle = "
+                      "pure-torch restatement of the PyG CPU op sequence, torch threads = cores"}
+
+
+if __name__ == "__main__":
+    main()

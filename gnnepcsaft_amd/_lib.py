@@ -38,8 +38,9 @@ SIGNATURES = {
     "gnx_set_stream": (_i32, [_vp, _vp]),
     "gnx_last_error": (C.c_char_p, []),
     "gnx_abi_version": (_i32, []),
-    "gnx_prof_begin": (_i32, [_vp, _i32]),
-    "gnx_prof_end": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gnx_prof_begin": (_i32, [_vp, C.c_uint32]),
+    "gnx_prof_read": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gnx_prof_end": (_i32, [_vp]),
     "gnx_pack_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "gnx_pack_csr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "gnx_feature_code": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _vp, _vp, _vp, _sz]),

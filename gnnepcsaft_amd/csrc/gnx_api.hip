@@ -74,20 +74,22 @@ extern "C" int32_t gnx_check_range(gnx_handle* h) {
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_prof_begin(gnx_handle* h, int32_t kid) {
+extern "C" int32_t gnx_prof_begin(gnx_handle* h, uint32_t kernel_mask) {
   GNX_CHECK_ARG(h != nullptr, "gnx_prof_begin: handle is NULL");
-  GNX_CHECK_ARG(kid >= 0 && kid < GNX_K_COUNT, "gnx_prof_begin: bad kernel id %d", kid);
-  h->prof_kid = kid;
+  GNX_CHECK_ARG((kernel_mask >> GNX_K_COUNT) == 0, "gnx_prof_begin: bad kernel mask 0x%x", kernel_mask);
+  h->prof_mask = kernel_mask & ~1u;
   h->ev_used = 0;
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_prof_end(gnx_handle* h, int64_t* launches, double* total_ms) {
-  GNX_CHECK_ARG(h != nullptr && launches != nullptr && total_ms != nullptr, "gnx_prof_end: NULL argument");
+extern "C" int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms) {
+  GNX_CHECK_ARG(h != nullptr && launches != nullptr && total_ms != nullptr, "gnx_prof_read: NULL argument");
+  GNX_CHECK_ARG(kid > 0 && kid < GNX_K_COUNT, "gnx_prof_read: bad kernel id %d", kid);
   GNX_HIP(hipStreamSynchronize(h->stream));
   double tot = 0.0;
   int64_t n = 0;
   for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    if (h->ev_kid[i / 2] != kid) continue;
     float ms = 0.f;
     GNX_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     tot += ms;
@@ -95,7 +97,12 @@ extern "C" int32_t gnx_prof_end(gnx_handle* h, int64_t* launches, double* total_
   }
   *launches = n;
   *total_ms = tot;
-  h->prof_kid = GNX_K_NONE;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_prof_end(gnx_handle* h) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_prof_end: handle is NULL");
+  h->prof_mask = 0;
   h->ev_used = 0;
   return GNX_OK;
 }

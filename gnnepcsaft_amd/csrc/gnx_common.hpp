@@ -15,9 +15,10 @@ struct gnx_handle {
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;
   float* d_scratch = nullptr;  // 4 KiB
-  // profiling
-  int prof_kid = GNX_K_NONE;
+  // profiling: bit k of prof_mask = record an event pair around every launch group of kernel id k
+  unsigned prof_mask = 0;
   std::vector<hipEvent_t> ev;
+  std::vector<int> ev_kid;  // kernel id of the event pair starting at ev[2*i]
   size_t ev_used = 0;
 };
 
@@ -53,8 +54,12 @@ void gnx_set_error(const char* fmt, ...);
 struct gnx_prof_scope {
   gnx_handle* h;
   bool on;
-  gnx_prof_scope(gnx_handle* h_, int kid) : h(h_), on(h_->prof_kid == kid && kid != GNX_K_NONE) {
-    if (on) mark();
+  gnx_prof_scope(gnx_handle* h_, int kid) : h(h_), on(((h_->prof_mask >> kid) & 1u) != 0 && kid != GNX_K_NONE) {
+    if (on) {
+      if (h->ev_kid.size() <= h->ev_used / 2) h->ev_kid.resize(h->ev_used / 2 + 1);
+      h->ev_kid[h->ev_used / 2] = kid;
+      mark();
+    }
   }
   ~gnx_prof_scope() {
     if (on) mark();

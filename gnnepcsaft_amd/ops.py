@@ -331,11 +331,20 @@ def clip_rows(x: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor) -> torch.Tens
     return y
 
 
-def prof_begin(device: torch.device, kernel_id: int) -> None:
-    check(_lib.load().gnx_prof_begin(handle(device), kernel_id))
+def prof_begin(device: torch.device, kernel_ids: Sequence[int]) -> None:
+    """Record HIP event pairs (on the stream the kernels run on) around every launch of the given GNX_K_* kernels."""
+    mask = 0
+    for k in kernel_ids:
+        mask |= 1 << k
+    check(_lib.load().gnx_prof_begin(handle(device), mask))
 
 
-def prof_end(device: torch.device) -> Tuple[int, float]:
+def prof_read(device: torch.device, kernel_id: int) -> Tuple[int, float]:
+    """(launches, total milliseconds) of one kernel id since prof_begin; synchronises."""
     n, ms = C.c_int64(0), C.c_double(0.0)
-    check(_lib.load().gnx_prof_end(handle(device), C.byref(n), C.byref(ms)))
+    check(_lib.load().gnx_prof_read(handle(device), kernel_id, C.byref(n), C.byref(ms)))
     return n.value, ms.value
+
+
+def prof_end(device: torch.device) -> None:
+    check(_lib.load().gnx_prof_end(handle(device)))

@@ -61,10 +61,13 @@ enum {
   GNX_K_BN_BWD = 10,
   GNX_K_COUNT = 11
 };
-/* start recording an event pair around every launch of kernel `kid` (GNX_K_NONE disables). */
-int32_t gnx_prof_begin(gnx_handle* h, int32_t kid);
-/* synchronise the stream, return #launches seen and their summed duration in milliseconds, and stop recording. */
-int32_t gnx_prof_end(gnx_handle* h, int64_t* launches, double* total_ms);
+/* start recording a HIP event pair around every launch of the kernels whose id bit is set in kernel_mask
+ * (bit k = GNX_K_* id k).  Events go on the handle's stream, i.e. the stream the kernels run on. */
+int32_t gnx_prof_begin(gnx_handle* h, uint32_t kernel_mask);
+/* synchronise the stream; #launches of kernel `kid` seen since gnx_prof_begin and their summed duration (ms). */
+int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms);
+/* stop recording and drop the recorded events. */
+int32_t gnx_prof_end(gnx_handle* h);
 
 /* ---- input packer: PyG-style COO batch -> dst-sorted CSR (+ by-source index) ------------------------------- */
 /* Replaces what PNAConv/GINEConv's MessagePassing.propagate [3P] does implicitly with edge_index on every call
