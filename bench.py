@@ -128,7 +128,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] gpu: {args.steps} steps in {elapsed:.3f}s, loss {loss_val:.6f}", file=sys.stderr, flush=True)
     assert loss_val == loss_val, "loss is NaN"
 
     if rank == 0:
@@ -179,17 +181,42 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores() -> int:
+    """Threads this process may really use: min(affinity, cgroup CPU quota); a GPU box shares its host between
+    8 GPUs (16 cores per GPU), and oversubscribing torch threads beyond the quota makes the CPU run far slower."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    elif n > 32:
+        n = 16  # no quota visible on a many-core host: stay within one GPU's CPU share
+    return n
+
+
 def cpu_baseline(cfg, deg, batch_cpu, steps):
     """The oracle (pure-torch restatement of the reference's PyG CPU op sequence; PyG itself is not installable here)
     timed on the host cores: zero_grad -> forward -> APE-Huber -> backward, same batch, fp32, all cores."""
     import copy
     from oracle import pyg_restatement as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline on {cores} host threads ...", file=sys.stderr, flush=True)
     c = copy.deepcopy(cfg)
     c["deg"] = deg
     torch.manual_seed(0)
@@ -207,7 +234,8 @@ def cpu_baseline(cfg, deg, batch_cpu, steps):
         dt = time.perf_counter() - t0
         if i > 0:
             times.append(dt)
-        if time.perf_counter() - budget_t0 > 60 and times:
+        print(f"[bench] cpu step {i}: {dt:.2f}s", file=sys.stderr, flush=True)
+        if time.perf_counter() - budget_t0 > 45 and times:
             break
     times.sort()
     med = times[len(times) // 2]
