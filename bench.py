@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="graphs per GPU (default: the config's batch / gpus rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-side-stream", action="store_true", help="keep weight-gradient kernels on the main stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +89,8 @@ def main():
     model.model.validate_inputs = False  # range flag is read back once per step below (no sync inside the step)
     dp.broadcast_parameters(model)
     flat = dp.FlatGradAllReduce(model)
+    Fn.set_grad_in_place(True)  # weight-gradient kernels accumulate straight into the flat all-reduce buffer
+    ops.set_wgrad_side_stream(not args.no_side_stream)  # wgrad kernels overlap the dgrad chain on a second stream
     b = batch_cpu.to(dev)
     N_nodes, E_edges = b.x.size(0), b.edge_index.size(1)
     H, T = cfg["hidden_dim"], cfg["towers"]

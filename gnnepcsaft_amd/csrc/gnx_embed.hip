@@ -70,7 +70,7 @@ extern "C" int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t 
 // grid = (row chunks, column slabs of CW).  Block: 256 threads = (256/CW) row lanes x CW columns.
 // LDS table R x CW accumulated with ds_add_f32, flushed with one global atomic per touched element.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename IdxT>
+template <typename IdxT, int VEC>
 __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restrict__ idx, int64_t N, int K, offs_t offs,
                                                            int R, const float* __restrict__ dout, int H, int CW,
                                                            int64_t rows_per_block, float* __restrict__ dtable) {
@@ -78,21 +78,46 @@ __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restric
   const int tid = threadIdx.x;
   for (int i = tid; i < R * CW; i += 256) lds[i] = 0.f;
   __syncthreads();
-  const int c = tid % CW;
-  const int rl = tid / CW;
-  const int RL = 256 / CW;
+  const int G = CW / VEC;        // threads per row
+  const int cg = tid % G;
+  const int rl = tid / G;
+  const int RL = 256 / G;        // rows in flight per pass
+  const int c = cg * VEC;        // column inside the slab
   const int col = blockIdx.y * CW + c;
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > N) r1 = N;
   if (col < H) {
-    for (int64_t n = r0 + rl; n < r1; n += RL) {
-      float g = dout[n * H + col];
+    // two rows in flight per thread: the loop is latency-bound otherwise (few hundred rows per block)
+    for (int64_t n = r0 + rl; n < r1; n += 2 * RL) {
+      const int64_t n2 = n + RL;
+      const bool has2 = n2 < r1;
+      float g0[VEC], g1[VEC];
+      if constexpr (VEC == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(dout + n * H + col);
+        g0[0] = v.x; g0[1] = v.y; g0[2] = v.z; g0[3] = v.w;
+        if (has2) {
+          f32x4 w = *reinterpret_cast<const f32x4*>(dout + n2 * H + col);
+          g1[0] = w.x; g1[1] = w.y; g1[2] = w.z; g1[3] = w.w;
+        }
+      } else {
+        g0[0] = dout[n * H + col];
+        if (has2) g1[0] = dout[n2 * H + col];
+      }
       for (int k = 0; k < K; ++k) {
-        int64_t f = (int64_t)idx[n * K + k];
-        int rows = offs.o[k + 1] - offs.o[k];
-        if (f < 0 || f >= rows) continue;  // flagged in forward
-        atomicAdd(&lds[(offs.o[k] + (int)f) * CW + c], g);
+        const int rows = offs.o[k + 1] - offs.o[k];
+        int64_t f0 = (int64_t)idx[n * K + k];
+        int64_t f1 = has2 ? (int64_t)idx[n2 * K + k] : -1;
+        if (f0 >= 0 && f0 < rows) {  // out-of-range indices were flagged in forward
+          float* d = &lds[(offs.o[k] + (int)f0) * CW + c];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) atomicAdd(d + v, g0[v]);
+        }
+        if (f1 >= 0 && f1 < rows) {
+          float* d = &lds[(offs.o[k] + (int)f1) * CW + c];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) atomicAdd(d + v, g1[v]);
+        }
       }
     }
   }
@@ -113,12 +138,16 @@ static int32_t launch_table_scatter_add(gnx_handle* h, const IdxT* idx, int64_t 
   while ((size_t)R * CW * sizeof(float) > 64 * 1024 && CW > 8) CW >>= 1;
   GNX_CHECK_ARG((size_t)R * CW * sizeof(float) <= 64 * 1024, "table scatter-add: %d rows do not fit the LDS tile", R);
   int slabs = (int)gnx_cdiv(H, CW);
-  // enough blocks to fill the chip, at least 256 rows each so the flush stays a small fraction
-  int64_t rows_per_block = gnx_cdiv(N, gnx_cdiv(1024, slabs));
+  // ~768 blocks (3 per CU) in total; at least 256 rows each so the R x CW atomic flush stays a small fraction
+  int64_t rows_per_block = gnx_cdiv(N, gnx_cdiv(768, slabs));
   if (rows_per_block < 256) rows_per_block = 256;
   int64_t chunks = gnx_cdiv(N, rows_per_block);
-  hipLaunchKernelGGL(k_table_scatter_add<IdxT>, dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
-                     (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
+  if (H % 4 == 0)
+    hipLaunchKernelGGL((k_table_scatter_add<IdxT, 4>), dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
+                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
+  else
+    hipLaunchKernelGGL((k_table_scatter_add<IdxT, 1>), dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
+                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

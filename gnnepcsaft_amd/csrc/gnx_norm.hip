@@ -44,21 +44,46 @@ __global__ void __launch_bounds__(256) k_bn_partial(const float* __restrict__ x,
   }
 }
 
-// one thread per column: fold chunks, derive mean/rstd, update running stats, emit alpha/beta'
+// Fold the per-chunk partials of 16 columns with 16 lanes per column (lane l takes chunks l, l+16, ... in order, then
+// the 16 lane sums are added in lane order): deterministic, ~chunks/16 dependent loads instead of `chunks`.
+// blockDim = 256 = 16 chunk-lanes (y) x 16 columns (x); returns the totals to the y == 0 threads.
+__device__ __forceinline__ void bn_fold(const float* __restrict__ part, int64_t chunks, int H, int c, float& t1,
+                                        float& t2) {
+  __shared__ float f1[16][17], f2[16][17];
+  const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < H) {
+    for (int64_t b = ly; b < chunks; b += 16) {
+      a1 += part[(b * 2 + 0) * H + c];
+      a2 += part[(b * 2 + 1) * H + c];
+    }
+  }
+  f1[ly][cx] = a1;
+  f2[ly][cx] = a2;
+  __syncthreads();
+  t1 = 0.f;
+  t2 = 0.f;
+  if (ly == 0) {
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      t1 += f1[l][cx];
+      t2 += f2[l][cx];
+    }
+  }
+}
+
+// 16 lanes per column fold the chunks; lane 0 derives mean/rstd, updates running stats, emits alpha/beta'
 __global__ void k_bn_finalize(const float* __restrict__ x, const float* __restrict__ part, int64_t chunks, int64_t M,
                               int H, const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                               float eps, int training, float* __restrict__ save_mean, float* __restrict__ save_rstd,
                               float* __restrict__ ab) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  float t1 = 0.f, t2 = 0.f;
+  if (training) bn_fold(part, chunks, H, c, t1, t2);
+  if (c >= H || (threadIdx.x >> 4) != 0) return;
   float mean, var;
   if (training) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int64_t b = 0; b < chunks; ++b) {
-      t1 += part[(b * 2 + 0) * H + c];
-      t2 += part[(b * 2 + 1) * H + c];
-    }
     const float inv = 1.0f / (float)M;
     const float d = t1 * inv;
     mean = x[c] + d;
@@ -127,7 +152,7 @@ extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, i
                        (int)H, part);
     GNX_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)gnx_cdiv(H, 64)), dim3(64), 0, h->stream, x, part, chunks, M, (int)H,
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)gnx_cdiv(H, 16)), dim3(256), 0, h->stream, x, part, chunks, M, (int)H,
                      gamma, beta, running_mean, running_var, momentum, eps, (int)training, save_mean, save_rstd, ab);
   GNX_LAUNCH_CHECK();
   int64_t total = M * H;
@@ -180,13 +205,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial(const float* __restrict_
 __global__ void k_bn_bwd_finalize(const float* __restrict__ part, int64_t chunks, int64_t M, int H,
                                   const float* __restrict__ gamma, const float* __restrict__ rstd,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   float t1 = 0.f, t2 = 0.f;
-  for (int64_t b = 0; b < chunks; ++b) {
-    t1 += part[(b * 2 + 0) * H + c];
-    t2 += part[(b * 2 + 1) * H + c];
-  }
+  bn_fold(part, chunks, H, c, t1, t2);
+  if (c >= H || (threadIdx.x >> 4) != 0) return;
   if (dbeta) dbeta[c] += t1;
   if (dgamma) dgamma[c] += t2;
   const float inv = 1.0f / (float)M;
@@ -227,7 +249,7 @@ extern "C" int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, dy, x,
                      y, M, (int)H, save_mean, save_rstd, (int)relu, part);
   GNX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)gnx_cdiv(H, 64)), dim3(64), 0, h->stream, part, chunks, M, (int)H,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)gnx_cdiv(H, 16)), dim3(256), 0, h->stream, part, chunks, M, (int)H,
                      gamma, save_rstd, dgamma, dbeta, coef);
   GNX_LAUNCH_CHECK();
   int64_t total = M * H;

@@ -14,6 +14,31 @@ from . import ops
 from .ops import GraphPack
 
 
+_GRAD_IN_PLACE = False
+
+
+def set_grad_in_place(enabled: bool) -> None:
+    """Opt-in: weight-gradient kernels accumulate (+=) straight into an existing ``param.grad`` (e.g. the views of
+    ``dp.FlatGradAllReduce``'s flat buffer) and the Functions return ``None`` for those parameters, instead of
+    materialising a zero-filled gradient per parameter per layer for autograd to add.  Same result as autograd's own
+    accumulation for the usual ``loss.backward()`` loop; leave it off when calling ``torch.autograd.grad``."""
+    global _GRAD_IN_PLACE
+    _GRAD_IN_PLACE = bool(enabled)
+
+
+def grad_sinks(params: Sequence[torch.Tensor]) -> tuple:
+    """Per parameter: its ``.grad`` buffer if in-place accumulation is enabled and usable, else ``None``."""
+    if not _GRAD_IN_PLACE:
+        return tuple(None for _ in params)
+    out = []
+    for p in params:
+        g = p.grad
+        ok = g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and \
+            g.device == p.device
+        out.append(g if ok else None)
+    return tuple(out)
+
+
 def _empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
 
@@ -45,6 +70,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.sinks = grad_sinks([weight] + ([bias] if bias is not None else []))
         y = _empty(x.size(0), weight.size(0), x)
         return ops.gemm([(x, None, weight)], y, bias=bias)
 
@@ -52,13 +78,18 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dw = _zeros_like(weight)
-        db = torch.zeros(weight.size(0), dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+        sw = ctx.sinks[0]
+        sb = ctx.sinks[1] if ctx.has_bias else None
+        dw = sw if sw is not None else _zeros_like(weight)
+        db = None
+        if ctx.has_bias:
+            db = sb if sb is not None else torch.zeros(weight.size(0), dtype=torch.float32, device=dy.device)
         ops.gemm_wgrad(dy, x, dw, dbias=db)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm([(dy, None, weight)], _empty(x.size(0), x.size(1), x), b_trans=False)
-        return dx, dw, db
+        ops.join_side_stream(dy.device)
+        return dx, (None if sw is not None else dw), (None if (sb is not None or not ctx.has_bias) else db)
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -70,6 +101,7 @@ class BatchNormFn(torch.autograd.Function):
         y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         ctx.relu, ctx.training = relu, training
+        ctx.sinks = grad_sinks([gamma, beta])
         return y
 
     @staticmethod
@@ -77,8 +109,10 @@ class BatchNormFn(torch.autograd.Function):
         x, y, gamma, mean, rstd = ctx.saved_tensors
         if not ctx.training:
             raise NotImplementedError("BatchNorm backward in eval mode is not on the reference's training path")
-        dx, dgamma, dbeta = ops.batchnorm_bwd(dy.contiguous(), x, y, gamma, mean, rstd, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        sg, sb = ctx.sinks
+        dx, dgamma, dbeta = ops.batchnorm_bwd(dy.contiguous(), x, y, gamma, mean, rstd, ctx.relu, dgamma=sg, dbeta=sb)
+        return dx, (None if sg is not None else dgamma), (None if sb is not None else dbeta), None, None, None, None, \
+            None, None
 
 
 class SegmentPoolFn(torch.autograd.Function):
@@ -175,6 +209,7 @@ class PNAConvFn(torch.autograd.Function):
         out = ops.gemm([(z, None, lin_w)], _empty(N, H, x), bias=lin_b)
         ctx.pack, ctx.cfg = pack, cfg
         ctx.n_h, ctx.n_z = len(hs), len(zs)
+        ctx.sinks = grad_sinks(params)
         ctx.save_for_backward(x, BE, EE, A, amp, att, *hs, *zs, *params)
         return out
 
@@ -191,7 +226,8 @@ class PNAConvFn(torch.autograd.Function):
         E, R = pack.E, BE.size(0)
         enc_w, enc_b, lin_w, lin_b = params[:4]
         per = 2 * (pre_layers + post_layers)
-        grads = [_zeros_like(p) for p in params]
+        sinks = ctx.sinks
+        grads = [sk if sk is not None else _zeros_like(p) for p, sk in zip(params, sinks)]
         d_enc_w, d_enc_b, d_lin_w, d_lin_b = grads[:4]
 
         def pidx(t, kind, i):  # index of (w) in params/grads
@@ -249,7 +285,8 @@ class PNAConvFn(torch.autograd.Function):
                       (dQ[:, sl[t]], None, W0[:, F:2 * F])], dx[:, sl[t]], b_trans=False)
         ops.gemm_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
         dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
-        return (dx, dBE, None, None, *grads)
+        ops.join_side_stream(x.device)
+        return (dx, dBE, None, None, *[None if sk is not None else g_ for g_, sk in zip(grads, sinks)])
 
 
 class GINEConvFn(torch.autograd.Function):
@@ -267,6 +304,7 @@ class GINEConvFn(torch.autograd.Function):
         a1 = ops.gemm([(agg, None, w0)], _empty(N, w0.size(0), x), bias=b0, relu=True)
         out = ops.gemm([(a1, None, w2)], _empty(N, w2.size(0), x), bias=b2)
         ctx.pack, ctx.eps = pack, eps
+        ctx.sinks = grad_sinks([lin_w, lin_b, w0, b0, w2, b2])
         ctx.save_for_backward(x, BE, Le, agg, a1, lin_w, w0, w2)
         return out
 
@@ -277,9 +315,13 @@ class GINEConvFn(torch.autograd.Function):
         dout = dout.contiguous()
         N, H = x.shape
         dev = dict(dtype=torch.float32, device=x.device)
-        dw2, db2 = _zeros_like(w2), torch.zeros(w2.size(0), **dev)
-        dw0, db0 = _zeros_like(w0), torch.zeros(w0.size(0), **dev)
-        dlw, dlb = _zeros_like(lin_w), torch.zeros(lin_w.size(0), **dev)
+        sk = ctx.sinks
+        dlw = sk[0] if sk[0] is not None else _zeros_like(lin_w)
+        dlb = sk[1] if sk[1] is not None else torch.zeros(lin_w.size(0), **dev)
+        dw0 = sk[2] if sk[2] is not None else _zeros_like(w0)
+        db0 = sk[3] if sk[3] is not None else torch.zeros(w0.size(0), **dev)
+        dw2 = sk[4] if sk[4] is not None else _zeros_like(w2)
+        db2 = sk[5] if sk[5] is not None else torch.zeros(w2.size(0), **dev)
         ops.gemm_wgrad(dout, a1, dw2, dbias=db2)
         g1 = ops.gemm([(dout, None, w2)], _empty(N, a1.size(1), x), b_trans=False, mask=a1)
         ops.gemm_wgrad(g1, agg, dw0, dbias=db0)
@@ -287,4 +329,6 @@ class GINEConvFn(torch.autograd.Function):
         dx, dLe = ops.gine_aggregate_bwd(dagg, x, Le, pack, ctx.eps)
         ops.gemm_wgrad(dLe, BE, dlw, dbias=dlb)
         dBE = ops.gemm([(dLe, None, lin_w)], _empty(BE.size(0), BE.size(1), x), b_trans=False)
-        return dx, dBE, None, None, dlw, dlb, dw0, db0, dw2, db2
+        ops.join_side_stream(x.device)
+        outs = [None if k is not None else g_ for g_, k in zip((dlw, dlb, dw0, db0, dw2, db2), sk)]
+        return (dx, dBE, None, None, *outs)

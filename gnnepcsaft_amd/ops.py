@@ -187,12 +187,52 @@ def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor]
     return out
 
 
+_SIDE_STREAMS = {}
+_SIDE_ENABLED = False
+_SIDE_PENDING = set()
+
+
+def set_wgrad_side_stream(enabled: bool) -> None:
+    """Run weight-gradient kernels on a second HIP stream so they overlap the input-gradient chain (the two are
+    independent inside a layer's backward).  Every autograd Function joins the side stream before it returns."""
+    global _SIDE_ENABLED
+    _SIDE_ENABLED = bool(enabled)
+
+
+def join_side_stream(device: torch.device) -> None:
+    """Make the current stream wait for all weight-gradient kernels issued on the side stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _SIDE_PENDING:
+        torch.cuda.current_stream(idx).wait_stream(_SIDE_STREAMS[idx])
+        _SIDE_PENDING.discard(idx)
+
+
 def gemm_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale: Optional[torch.Tensor] = None,
                dbias: Optional[torch.Tensor] = None) -> None:
     """dW[N,K] += dC[M,N]^T @ (rowscale * A[M,K]);  dbias[N] += column sums of dC."""
     M, N = dC.shape
     if M == 0:
         return
+    if _SIDE_ENABLED and dC.is_cuda:
+        idx = dC.device.index
+        side = _SIDE_STREAMS.get(idx)
+        if side is None:
+            side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        main = torch.cuda.current_stream(idx)
+        if main != side:
+            side.wait_stream(main)  # operands were produced on the main stream
+            for t in (dC, A, rowscale):
+                if t is not None:
+                    t.record_stream(side)  # keep the allocator from recycling them under the side kernel
+            _SIDE_PENDING.add(idx)
+            with torch.cuda.stream(side):
+                _gemm_wgrad_launch(dC, A, dW, rowscale, dbias)
+            return
+    _gemm_wgrad_launch(dC, A, dW, rowscale, dbias)
+
+
+def _gemm_wgrad_launch(dC, A, dW, rowscale, dbias) -> None:
+    M, N = dC.shape
     xp, ldx = _mat(dC, "dC")
     ap, lda = _mat(A, "A")
     wp, ldw = _mat(dW, "dW")
@@ -299,11 +339,14 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum: float, ep
     return y, mean, rstd
 
 
-def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu: bool):
+def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu: bool, dgamma=None, dbeta=None):
+    """dgamma / dbeta: optional existing buffers to accumulate (+=) into; fresh zero buffers otherwise."""
     M, H = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.zeros(H, dtype=torch.float32, device=x.device)
-    dbeta = torch.zeros(H, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.zeros(H, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.zeros(H, dtype=torch.float32, device=x.device)
     ws, nbytes = _bn_ws(M, H, x.device)
     check(_lib.load().gnx_batchnorm_bwd(handle(x.device), dy.data_ptr(), x.data_ptr(), y.data_ptr(), M, H, _ptr(gamma),
                                         mean.data_ptr(), rstd.data_ptr(), int(relu), dx.data_ptr(), dgamma.data_ptr(),

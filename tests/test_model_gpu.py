@@ -126,6 +126,40 @@ def test_hip_path_against_committed_golden_vectors(gpu_device, name):
     assert rel_err(native.batch_norms[0].module.running_mean, torch.from_numpy(gold["running_mean.0"])) <= 1e-4
 
 
+@pytest.mark.parametrize("conv", ["PNA", "GINE"])
+def test_grad_in_place_into_flat_buffer_equals_autograd_accumulation(gpu_device, conv):
+    """dp.FlatGradAllReduce + Fn.set_grad_in_place(True): weight-gradient kernels accumulate into the flat buffer."""
+    from gnnepcsaft_amd import dp, functional as Fn
+    from gnnepcsaft_amd.data import calc_deg, synthetic_batch
+    from gnnepcsaft_amd.train.models import create_model
+    cfg = _cfg(conv=conv, hidden_dim=32, towers=2 if conv == "PNA" else 1, propagation_depth=2)
+    batch = synthetic_batch(16, 2)
+    deg = calc_deg(batch)
+    b = batch.to("cuda:0")
+    torch.manual_seed(0)
+    m1 = create_model(copy.deepcopy(cfg), deg).to("cuda:0")
+    m2 = create_model(copy.deepcopy(cfg), deg).to("cuda:0")
+    m2.load_state_dict(m1.state_dict())
+    m1.training_step(b, 0).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in m1.parameters()])
+    flat = dp.FlatGradAllReduce(m2)
+    from gnnepcsaft_amd import ops
+    try:
+        Fn.set_grad_in_place(True)
+        ops.set_wgrad_side_stream(True)  # weight-gradient kernels on a second stream, joined per Function
+        for _ in range(2):  # second round checks zero_grad() + re-accumulation
+            flat.zero_grad()
+            b._gnx_pack = None
+            m2.training_step(b, 0).backward()
+        flat.all_reduce()  # world size 1: no-op
+    finally:
+        Fn.set_grad_in_place(False)
+        ops.set_wgrad_side_stream(False)
+    torch.cuda.synchronize()
+    assert flat.nbytes == ref.numel() * 4
+    assert rel_err(flat.flat, ref) <= 1e-5
+
+
 def test_eval_inference_batch_none_and_bounds(gpu_device):
     """Inference form of demo/utils.py:899,950: eval mode, batch=None, pred_with_bounds clip (models.py:229-254)."""
     from gnnepcsaft_amd.data import calc_deg, synthetic_batch
