@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-side-stream", action="store_true", help="keep weight-gradient kernels on the main stream")
+    ap.add_argument("--no-degree-classes", action="store_true", help="PNA post-layer 0 as the 13F-wide 4-segment product")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,6 +92,7 @@ def main():
     flat = dp.FlatGradAllReduce(model)
     Fn.set_grad_in_place(True)  # weight-gradient kernels accumulate straight into the flat all-reduce buffer
     ops.set_wgrad_side_stream(not args.no_side_stream)  # wgrad kernels overlap the dgrad chain on a second stream
+    Fn.set_degree_classes(not args.no_degree_classes)
     b = batch_cpu.to(dev)
     N_nodes, E_edges = b.x.size(0), b.edge_index.size(1)
     H, T = cfg["hidden_dim"], cfg["towers"]

@@ -28,6 +28,7 @@ struct seg_dev {
   const float* b;
   int64_t lda;
   int64_t ldb;
+  int64_t cls_stride;  // grouped mode: B of class c starts at b + c * cls_stride (0 = class-independent)
   int k;
   int vec_a;  // 1: float4 loads allowed on A (16B-aligned rows)
   int vec_b;
@@ -45,6 +46,11 @@ struct gemm_args {
   int64_t ldc;
   int relu;
   int accumulate;
+  // grouped mode (degree classes): workgroup b handles rows row_index[tile_info[3b] .. +tile_info[3b+1]) with the
+  // class-tile_info[3b+2] weights; workgroups >= *ntiles exit.  NULL tile_info = plain row tiles.
+  const int* row_index;
+  const int* tile_info;
+  const int* ntiles;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int valid) {
@@ -71,8 +77,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  __shared__ int rid[BM];  // global row of every tile row (-1 = padding)
+  int cls = 0;
+  if (g.tile_info != nullptr) {
+    if ((int)blockIdx.x >= g.ntiles[0]) return;
+    const int p0 = g.tile_info[3 * blockIdx.x], pr = g.tile_info[3 * blockIdx.x + 1];
+    cls = g.tile_info[3 * blockIdx.x + 2];
+    if (tid < BM) rid[tid] = (tid < pr) ? g.row_index[p0 + tid] : -1;
+  } else {
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    if (tid < BM) rid[tid] = (m0 + tid < g.M) ? (int)(m0 + tid) : -1;
+  }
+  __syncthreads();
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -91,14 +108,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   // loader geometry for the k-row image (NN B): 32 lanes cover 128 columns, 8 k-rows per pass, 4 passes
   const int br = tid >> 5;        // 0..7
   const int bc = (tid & 31) * 4;  // 0..124
+  int grow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) grow[i] = rid[lr + 32 * i];
 
   auto load_tile = [&](const seg_dev& s, int k0) {
+    const float* sb = s.b + (int64_t)cls * s.cls_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int r = lr + 32 * i;
-      int64_t gm = m0 + r;
+      int64_t gm = grow[i];
       int kv = s.k - (k0 + lk);
-      kv = gm < g.M ? kv : 0;
+      kv = gm >= 0 ? kv : 0;
       f32x4 v = ld4(s.a + gm * s.lda + k0 + lk, s.vec_a, kv);
       if (s.rs != nullptr && kv > 0) {
         float sc = s.rs[gm];
@@ -116,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
         int gn = n0 + r;
         int kv = s.k - (k0 + lk);
         kv = gn < g.N ? kv : 0;
-        rb[i] = ld4(s.b + (int64_t)gn * s.ldb + k0 + lk, s.vec_b, kv);
+        rb[i] = ld4(sb + (int64_t)gn * s.ldb + k0 + lk, s.vec_b, kv);
       }
     } else {
 #pragma unroll
@@ -124,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
         int kr = br + 8 * i;
         int nv = g.N - (n0 + bc);
         nv = (k0 + kr) < s.k ? nv : 0;
-        rb[i] = ld4(s.b + (int64_t)(k0 + kr) * s.ldb + n0 + bc, s.vec_b, nv);
+        rb[i] = ld4(sb + (int64_t)(k0 + kr) * s.ldb + n0 + bc, s.vec_b, nv);
       }
     }
   };
@@ -207,8 +227,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
       float bv = g.bias ? g.bias[gc] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int64_t gr = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (gr >= g.M) continue;
+        int64_t gr = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        if (gr < 0) continue;
         float v = acc[mi][ni][r] + bv;
         float* cp = g.C + gr * g.ldc + gc;
         if (g.accumulate) v += *cp;
@@ -221,8 +241,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
-                            const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
+static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                           int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
+                           int64_t ldc, int32_t flags, const int32_t* row_index, const int32_t* tile_info,
+                           const int32_t* ntiles, int64_t max_tiles) {
   GNX_CHECK_ARG(h && segs && C, "gnx_gemm: NULL argument");
   GNX_CHECK_ARG(nseg >= 1 && nseg <= MAX_SEGS, "gnx_gemm: nseg=%d not in [1,%d]", nseg, MAX_SEGS);
   GNX_CHECK_ARG(M >= 0 && N > 0 && ldc >= N, "gnx_gemm: bad shape M=%lld N=%d ldc=%lld", (long long)M, N, (long long)ldc);
@@ -231,7 +253,7 @@ extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* seg
   if (M == 0) return GNX_OK;
   const bool bt = (flags & GNX_GEMM_B_TRANS) != 0;
   gemm_args g;
-  for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   for (int s = 0; s < nseg; ++s) {
     const gnx_gemm_seg& in = segs[s];
     GNX_CHECK_ARG(in.a && in.b && in.k > 0, "gnx_gemm: segment %d: NULL operand or k<=0", s);
@@ -243,9 +265,10 @@ extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* seg
     d.b = in.b;
     d.lda = in.lda;
     d.ldb = in.ldb;
+    d.cls_stride = cls_strides ? cls_strides[s] : 0;
     d.k = in.k;
     d.vec_a = aligned16(in.a) && (in.lda % 4 == 0);
-    d.vec_b = aligned16(in.b) && (in.ldb % 4 == 0);
+    d.vec_b = aligned16(in.b) && (in.ldb % 4 == 0) && (d.cls_stride % 4 == 0);
     g.seg[s] = d;
   }
   g.nseg = nseg;
@@ -258,7 +281,10 @@ extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* seg
   g.ldc = ldc;
   g.relu = (flags & GNX_GEMM_RELU) ? 1 : 0;
   g.accumulate = (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0;
-  dim3 grid((unsigned)gnx_cdiv(M, BM), (unsigned)gnx_cdiv(N, BN));
+  g.row_index = row_index;
+  g.tile_info = tile_info;
+  g.ntiles = ntiles;
+  dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM);
   if (bt)
     hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, h->stream, g);
@@ -266,6 +292,20 @@ extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* seg
     hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, h->stream, g);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
+}
+
+extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
+                            const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
+  return gemm_launch(h, nseg, segs, nullptr, M, N, bias, mask, ldmask, C, ldc, flags, nullptr, nullptr, nullptr, 0);
+}
+
+extern "C" int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                                    int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask,
+                                    float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
+                                    const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles) {
+  GNX_CHECK_ARG(cls_strides && row_index && tile_info && ntiles && max_tiles > 0, "gnx_gemm_grouped: NULL argument");
+  return gemm_launch(h, nseg, segs, cls_strides, M, N, bias, mask, ldmask, C, ldc, flags, row_index, tile_info, ntiles,
+                     max_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -285,6 +325,11 @@ struct wgrad_args {
   float* dbias;
   int64_t rows_per_block;
   int vec_x, vec_y;
+  // grouped mode: blockIdx.x = chunk; rows row_index[chunk_info[3b] .. +chunk_info[3b+1]) add into dW + class * stride
+  const int* row_index;
+  const int* chunk_info;
+  const int* nchunks;
+  int64_t dw_cls_stride;
 };
 
 __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
@@ -297,9 +342,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;  // dW row tile (output features)
   const int c0 = blockIdx.z * BN;  // dW col tile (input features)
-  const int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
+  int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
   int64_t r_end = r_begin + g.rows_per_block;
   if (r_end > g.M) r_end = g.M;
+  float* dW = g.dW;
+  if (g.chunk_info != nullptr) {
+    if ((int)blockIdx.x >= g.nchunks[0]) return;
+    r_begin = g.chunk_info[3 * blockIdx.x];
+    r_end = r_begin + g.chunk_info[3 * blockIdx.x + 1];
+    dW += (int64_t)g.chunk_info[3 * blockIdx.x + 2] * g.dw_cls_stride;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -319,6 +371,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
     for (int i = 0; i < 4; ++i) {
       int64_t gm = r0 + br + 8 * i;
       bool rv = gm < r_end;
+      if (g.row_index != nullptr && rv) gm = g.row_index[gm];
       int nv = rv ? g.N - (n0 + bc) : 0;
       rx[i] = ld4(g.X + gm * g.ldx + n0 + bc, g.vec_x, nv);
       int kv = rv ? g.K - (c0 + bc) : 0;
@@ -391,15 +444,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
       for (int r = 0; r < 16; ++r) {
         int gr = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (gr >= g.N) continue;
-        atomicAdd(g.dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
+        atomicAdd(dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
       }
     }
   if (g.dbias != nullptr && blockIdx.z == 0 && tid < BN && n0 + tid < g.N) atomicAdd(g.dbias + n0 + tid, bsum);
 }
 
-extern "C" int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
-                                  const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw,
-                                  float* dbias) {
+static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
+                            const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw,
+                            float* dbias, const int32_t* row_index, const int32_t* chunk_info, const int32_t* nchunks,
+                            int64_t max_chunks, int64_t dw_cls_stride) {
   GNX_CHECK_ARG(h && dC && A && dW, "gnx_gemm_wgrad: NULL argument");
   GNX_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lddc >= N && lda >= K && lddw >= K, "gnx_gemm_wgrad: bad shape");
   if (M == 0) return GNX_OK;
@@ -423,9 +477,89 @@ extern "C" int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, 
   int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
   if (rows < 128) rows = 128;
   g.rows_per_block = rows;
-  dim3 grid((unsigned)gnx_cdiv(M, rows), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
+  g.row_index = row_index;
+  g.chunk_info = chunk_info;
+  g.nchunks = nchunks;
+  g.dw_cls_stride = dw_cls_stride;
+  dim3 grid((unsigned)(chunk_info ? max_chunks : gnx_cdiv(M, rows)), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   hipLaunchKernelGGL(k_gemm_wgrad, grid, dim3(256), 0, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
+                                  const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw,
+                                  float* dbias) {
+  return wgrad_launch(h, dC, lddc, A, lda, rowscale, M, N, K, dW, lddw, dbias, nullptr, nullptr, nullptr, 0, 0);
+}
+
+extern "C" int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
+                                          int64_t M, int32_t N, int32_t K, float* dW_cls, int64_t lddw,
+                                          int64_t dw_cls_stride, const int32_t* row_index, const int32_t* chunk_info,
+                                          const int32_t* nchunks, int64_t max_chunks) {
+  GNX_CHECK_ARG(row_index && chunk_info && nchunks && max_chunks > 0, "gnx_gemm_wgrad_grouped: NULL argument");
+  return wgrad_launch(h, dC, lddc, A, lda, nullptr, M, N, K, dW_cls, lddw, nullptr, row_index, chunk_info, nchunks,
+                      max_chunks, dw_cls_stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PNA post-layer 0 effective weights per in-degree class d (amp/att depend on d only):
+//   Weff[d][o][j] = W[o][F + j] + amp(d) W[o][5F + j] + att(d) W[o][9F + j],   o < F, j < 4F
+// and the matching weight gradient:  dW[:, F:5F] += sum_d dWeff[d], [:, 5F:9F] += sum_d amp(d) dWeff[d], ...
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_pna_weff(const float* __restrict__ W, int64_t ldw, int F, int D, float avg_log,
+                           float* __restrict__ Weff) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t per = (int64_t)F * 4 * F;
+  if (i >= per * D) return;
+  int d = (int)(i / per);
+  int o = (int)((i % per) / (4 * F)), j = (int)(i % (4 * F));
+  float dd = (float)d;
+  float amp = logf(dd + 1.0f) / avg_log;
+  float att = avg_log / logf(fmaxf(dd, 1.0f) + 1.0f);
+  const float* w = W + (int64_t)o * ldw;
+  Weff[i] = w[F + j] + amp * w[5 * F + j] + att * w[9 * F + j];
+}
+
+__global__ void k_pna_weff_bwd(const float* __restrict__ dWeff, int F, int D, float avg_log, float* __restrict__ dW,
+                               int64_t lddw) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t per = (int64_t)F * 4 * F;
+  if (i >= per) return;
+  int o = (int)(i / (4 * F)), j = (int)(i % (4 * F));
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float dd = (float)d;
+    float amp = logf(dd + 1.0f) / avg_log;
+    float att = avg_log / logf(fmaxf(dd, 1.0f) + 1.0f);
+    float v = dWeff[(int64_t)d * per + i];
+    s1 += v;
+    s2 += amp * v;
+    s3 += att * v;
+  }
+  float* w = dW + (int64_t)o * lddw;
+  w[F + j] += s1;
+  w[5 * F + j] += s2;
+  w[9 * F + j] += s3;
+}
+
+extern "C" int32_t gnx_pna_weff(gnx_handle* h, const float* W, int64_t ldw, int32_t F, int32_t D, float avg_deg_log,
+                                float* Weff) {
+  GNX_CHECK_ARG(h && W && Weff && F > 0 && D > 0 && ldw >= 13 * F, "gnx_pna_weff: bad argument");
+  int64_t n = (int64_t)F * 4 * F * D;
+  hipLaunchKernelGGL(k_pna_weff, dim3((unsigned)gnx_cdiv(n, 256)), dim3(256), 0, h->stream, W, ldw, (int)F, (int)D,
+                     avg_deg_log, Weff);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_pna_weff_bwd(gnx_handle* h, const float* dWeff, int32_t F, int32_t D, float avg_deg_log,
+                                    float* dW, int64_t lddw) {
+  GNX_CHECK_ARG(h && dWeff && dW && F > 0 && D > 0 && lddw >= 13 * F, "gnx_pna_weff_bwd: bad argument");
+  int64_t n = (int64_t)F * 4 * F;
+  hipLaunchKernelGGL(k_pna_weff_bwd, dim3((unsigned)gnx_cdiv(n, 256)), dim3(256), 0, h->stream, dWeff, (int)F, (int)D,
+                     avg_deg_log, dW, lddw);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

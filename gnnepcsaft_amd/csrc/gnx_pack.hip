@@ -295,3 +295,126 @@ extern "C" int32_t gnx_degree_scalers(gnx_handle* h, const int32_t* rowptr, int6
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// In-degree classes: nodes stably sorted by in-degree (a deterministic counting sort: per-block histograms -> scan ->
+// stable ranks), and tile tables that never straddle two classes.  Lets PNA's post-layer 0 use one effective weight
+// W_eff(d) = W1 + amp(d) W2 + att(d) W3 per class instead of the 12F-wide scaled operand (amp/att depend on d only).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_degree_max(const int* __restrict__ rowptr, int64_t N, int* __restrict__ out) {
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int d = (n < N) ? rowptr[n + 1] - rowptr[n] : 0;
+  // wave max, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, d);
+}
+
+extern "C" int32_t gnx_degree_max(gnx_handle* h, const int32_t* rowptr, int64_t N, int32_t* max_degree_host) {
+  GNX_CHECK_ARG(h && max_degree_host && N >= 0 && (N == 0 || rowptr), "gnx_degree_max: bad argument");
+  int* d_out = h->d_flag + 8;  // scratch word inside the handle's flag block
+  GNX_HIP(hipMemsetAsync(d_out, 0, sizeof(int), h->stream));
+  if (N > 0) {
+    hipLaunchKernelGGL(k_degree_max, dim3((unsigned)gnx_cdiv(N, 256)), dim3(256), 0, h->stream, rowptr, N, d_out);
+    GNX_LAUNCH_CHECK();
+  }
+  int v = 0;
+  GNX_HIP(hipMemcpyAsync(&v, d_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GNX_HIP(hipStreamSynchronize(h->stream));
+  *max_degree_host = v;
+  return GNX_OK;
+}
+
+#define DC_BLOCK 256
+#define DC_MAX_CLASSES 64
+
+// blockhist[d * nblocks + b] = #nodes of block b with in-degree d
+__global__ void __launch_bounds__(DC_BLOCK) k_dc_hist(const int* __restrict__ rowptr, int64_t N, int D, int nblocks,
+                                                       int* __restrict__ blockhist) {
+  __shared__ int hist[DC_MAX_CLASSES];
+  if (threadIdx.x < DC_MAX_CLASSES) hist[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t n = (int64_t)blockIdx.x * DC_BLOCK + threadIdx.x;
+  if (n < N) {
+    int d = rowptr[n + 1] - rowptr[n];
+    if (d >= D) d = D - 1;  // cannot happen when D = max degree + 1
+    atomicAdd(&hist[d], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < D) blockhist[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// stable position of every node: scanned block offset of its (class, block) + rank among earlier same-class threads
+__global__ void __launch_bounds__(DC_BLOCK) k_dc_fill(const int* __restrict__ rowptr, int64_t N, int D, int nblocks,
+                                                       const int* __restrict__ blockoff, int* __restrict__ dperm,
+                                                       int* __restrict__ cls_ptr) {
+  __shared__ int degs[DC_BLOCK];
+  int64_t n = (int64_t)blockIdx.x * DC_BLOCK + threadIdx.x;
+  int d = -1;
+  if (n < N) {
+    d = rowptr[n + 1] - rowptr[n];
+    if (d >= D) d = D - 1;
+  }
+  degs[threadIdx.x] = d;
+  __syncthreads();
+  if (n < N) {
+    int rank = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) rank += (degs[t] == d) ? 1 : 0;
+    dperm[blockoff[d * nblocks + blockIdx.x] + rank] = (int)n;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x <= D)
+    cls_ptr[threadIdx.x] = ((int)threadIdx.x == D) ? (int)N : blockoff[threadIdx.x * nblocks];
+}
+
+extern "C" size_t gnx_degree_classes_workspace_bytes(int64_t N, int32_t D) {
+  if (N < 0) N = 0;
+  int64_t nblocks = gnx_cdiv(N > 0 ? N : 1, DC_BLOCK);
+  size_t ints = 2 * (size_t)(D * nblocks + 1) + scan_ws_ints_total(D * nblocks) + 64;
+  return ints * sizeof(int);
+}
+
+extern "C" int32_t gnx_degree_classes(gnx_handle* h, const int32_t* rowptr, int64_t N, int32_t D, int32_t* dperm,
+                                      int32_t* cls_ptr, void* ws, size_t ws_bytes) {
+  GNX_CHECK_ARG(h && rowptr && cls_ptr && N >= 0 && D >= 1 && D <= DC_MAX_CLASSES && (N == 0 || dperm),
+                "gnx_degree_classes: bad argument (D must be in [1,%d])", DC_MAX_CLASSES);
+  if (ws_bytes < gnx_degree_classes_workspace_bytes(N, D) || !ws) {
+    gnx_set_error("gnx_degree_classes: workspace %zu < %zu", ws_bytes, gnx_degree_classes_workspace_bytes(N, D));
+    return GNX_E_WORKSPACE;
+  }
+  int nblocks = (int)gnx_cdiv(N > 0 ? N : 1, DC_BLOCK);
+  int* blockhist = reinterpret_cast<int*>(ws);
+  int* blockoff = blockhist + (size_t)D * nblocks + 1;
+  int* scan_ws = blockoff + (size_t)D * nblocks + 1;
+  hipLaunchKernelGGL(k_dc_hist, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, N, (int)D, nblocks, blockhist);
+  GNX_LAUNCH_CHECK();
+  int32_t st = exclusive_scan(h, blockhist, blockoff, (int64_t)D * nblocks, scan_ws, false);
+  if (st != GNX_OK) return st;
+  hipLaunchKernelGGL(k_dc_fill, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, N, (int)D, nblocks, blockoff, dperm,
+                     cls_ptr);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// tile table: for class c, ceil(n_c / tile_rows) tiles of (first position in dperm, #rows, class); ntiles[0] = count
+__global__ void k_class_tiles(const int* __restrict__ cls_ptr, int D, int tile_rows, int* __restrict__ tile_info,
+                              int* __restrict__ ntiles) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int t = 0;
+  for (int c = 0; c < D; ++c) {
+    for (int r = cls_ptr[c]; r < cls_ptr[c + 1]; r += tile_rows) {
+      int rows = cls_ptr[c + 1] - r;
+      tile_info[3 * t + 0] = r;
+      tile_info[3 * t + 1] = rows < tile_rows ? rows : tile_rows;
+      tile_info[3 * t + 2] = c;
+      ++t;
+    }
+  }
+  ntiles[0] = t;
+}
+
+extern "C" int32_t gnx_class_tiles(gnx_handle* h, const int32_t* cls_ptr, int32_t D, int32_t tile_rows,
+                                   int32_t* tile_info, int32_t* ntiles) {
+  GNX_CHECK_ARG(h && cls_ptr && tile_info && ntiles && D >= 1 && tile_rows > 0, "gnx_class_tiles: bad argument");
+  hipLaunchKernelGGL(k_class_tiles, dim3(1), dim3(64), 0, h->stream, cls_ptr, (int)D, (int)tile_rows, tile_info, ntiles);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

@@ -15,6 +15,13 @@ from .ops import GraphPack
 
 
 _GRAD_IN_PLACE = False
+_USE_DEGREE_CLASSES = True
+
+
+def set_degree_classes(enabled: bool) -> None:
+    """A/B switch for PNA's per-degree-class post-layer 0 (default on; off = the 4-segment 13F-wide product)."""
+    global _USE_DEGREE_CLASSES
+    _USE_DEGREE_CLASSES = bool(enabled)
 
 
 def set_grad_in_place(enabled: bool) -> None:
@@ -193,11 +200,21 @@ class PNAConvFn(torch.autograd.Function):
         A = ops.pna_aggregate_fwd(h, pack, T, F)
         amp, att = pack.degree_scalers(avg_deg_log)
         z = _empty(N, H, x)
+        # post-layer 0: amp/att depend on the in-degree only, so with rows grouped by degree class the 12F-wide scaled
+        # operand collapses to A @ Weff(d)^T (26NF^2 -> 10NF^2 FLOPs); hub-heavy batches (>64 classes) keep 4 segments
+        dc = pack.degree_classes() if _USE_DEGREE_CLASSES else None
+        weffs = []
         for t in range(T):
             Wp, bp = post[t][0]
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
-            ops.gemm([(x[:, sl[t]], None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
-                      (At, att, Wp[:, 9 * F:13 * F])], z[:, sl[t]], bias=bp, relu=post_layers > 1)
+            if dc is not None:
+                weff = ops.pna_weff(Wp, F, dc.D, avg_deg_log)
+                weffs.append(weff)
+                ops.gemm_grouped([(x[:, sl[t]], None, Wp[:, 0:F], 0), (At, None, weff[0], 4 * F * F)], z[:, sl[t]], dc,
+                                 bias=bp, relu=post_layers > 1)
+            else:
+                ops.gemm([(x[:, sl[t]], None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
+                          (At, att, Wp[:, 9 * F:13 * F])], z[:, sl[t]], bias=bp, relu=post_layers > 1)
         zs = [z]
         for i in range(1, post_layers):
             zn = _empty(N, H, x)
@@ -210,6 +227,7 @@ class PNAConvFn(torch.autograd.Function):
         ctx.pack, ctx.cfg = pack, cfg
         ctx.n_h, ctx.n_z = len(hs), len(zs)
         ctx.sinks = grad_sinks(params)
+        ctx.dc, ctx.weffs = dc, weffs
         ctx.save_for_backward(x, BE, EE, A, amp, att, *hs, *zs, *params)
         return out
 
@@ -255,11 +273,16 @@ class PNAConvFn(torch.autograd.Function):
             gt = g[:, sl[t]]
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
             ops.gemm_wgrad(gt, x[:, sl[t]], dWp[:, 0:F], dbias=grads[k + 1])
-            ops.gemm_wgrad(gt, At, dWp[:, F:5 * F])
-            ops.gemm_wgrad(gt, At, dWp[:, 5 * F:9 * F], rowscale=amp)
-            ops.gemm_wgrad(gt, At, dWp[:, 9 * F:13 * F], rowscale=att)
-            ops.gemm([(gt, None, Wp[:, F:5 * F]), (gt, amp, Wp[:, 5 * F:9 * F]), (gt, att, Wp[:, 9 * F:13 * F])],
-                     dA[:, t * 4 * F:(t + 1) * 4 * F], b_trans=False)
+            if ctx.dc is not None:
+                ops.pna_post0_wgrad_classes(gt, At, ctx.dc, F, ctx.cfg[4], dWp)
+                ops.gemm_grouped([(gt, None, ctx.weffs[t][0], 4 * F * F)], dA[:, t * 4 * F:(t + 1) * 4 * F], ctx.dc,
+                                 b_trans=False)
+            else:
+                ops.gemm_wgrad(gt, At, dWp[:, F:5 * F])
+                ops.gemm_wgrad(gt, At, dWp[:, 5 * F:9 * F], rowscale=amp)
+                ops.gemm_wgrad(gt, At, dWp[:, 9 * F:13 * F], rowscale=att)
+                ops.gemm([(gt, None, Wp[:, F:5 * F]), (gt, amp, Wp[:, 5 * F:9 * F]), (gt, att, Wp[:, 9 * F:13 * F])],
+                         dA[:, t * 4 * F:(t + 1) * 4 * F], b_trans=False)
         ge = ops.pna_aggregate_bwd(dA, hs[-1], A, pack, T, F)
         for i in range(pre_layers - 1, 0, -1):
             h_prev = hs[i - 1]

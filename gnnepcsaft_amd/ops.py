@@ -50,7 +50,16 @@ class GraphPack:
     """
 
     __slots__ = ("N", "E", "B", "rowptr", "perm", "src", "dst", "colptr", "cpos", "code", "graph_ptr", "device",
-                 "_scalers", "has_batch")
+                 "_scalers", "has_batch", "_classes")
+
+    def degree_classes(self) -> Optional["DegreeClasses"]:
+        """Nodes grouped by in-degree (for PNA's per-degree effective post-layer-0 weight); ``None`` when the batch
+        has more than 64 distinct degrees up to its maximum (hub-heavy graphs use the ungrouped 4-segment product).
+        Built once per batch; reads the maximum in-degree back from the device (one sync, like PyG's
+        ``batch.max()``)."""
+        if self._classes is None:
+            self._classes = DegreeClasses.build(self)
+        return self._classes if self._classes.D <= DegreeClasses.MAX_D else None
 
     def degree_scalers(self, avg_deg_log: float) -> Tuple[torch.Tensor, torch.Tensor]:
         key = float(avg_deg_log)
@@ -63,6 +72,43 @@ class GraphPack:
             hit = (amp, att)
             self._scalers[key] = hit
         return hit
+
+
+class DegreeClasses:
+    """dperm / cls_ptr / tile tables of gnx_degree_classes + gnx_class_tiles (see include/gnx.h)."""
+    MAX_D = 64
+    GEMM_ROWS = 128    # k_gemm's BM
+    WGRAD_ROWS = 512   # rows per weight-gradient chunk
+
+    __slots__ = ("D", "dperm", "cls_ptr", "tiles", "ntiles", "max_tiles", "chunks", "nchunks", "max_chunks")
+
+    @staticmethod
+    def build(g: "GraphPack") -> "DegreeClasses":
+        lib, h = _lib.load(), handle(g.device)
+        dc = DegreeClasses()
+        mx = _I32(0)
+        check(lib.gnx_degree_max(h, g.rowptr.data_ptr(), g.N, C.byref(mx)))
+        dc.D = int(mx.value) + 1
+        if dc.D > DegreeClasses.MAX_D:
+            return dc
+        i32 = dict(dtype=torch.int32, device=g.device)
+        dc.dperm = torch.empty(max(g.N, 1), **i32)
+        dc.cls_ptr = torch.empty(dc.D + 1, **i32)
+        nbytes = lib.gnx_degree_classes_workspace_bytes(g.N, dc.D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        check(lib.gnx_degree_classes(h, g.rowptr.data_ptr(), g.N, dc.D, dc.dperm.data_ptr(), dc.cls_ptr.data_ptr(),
+                                     ws.data_ptr(), nbytes))
+        dc.max_tiles = g.N // DegreeClasses.GEMM_ROWS + dc.D
+        dc.max_chunks = g.N // DegreeClasses.WGRAD_ROWS + dc.D
+        dc.tiles = torch.empty(3 * dc.max_tiles, **i32)
+        dc.chunks = torch.empty(3 * dc.max_chunks, **i32)
+        dc.ntiles = torch.empty(1, **i32)
+        dc.nchunks = torch.empty(1, **i32)
+        check(lib.gnx_class_tiles(h, dc.cls_ptr.data_ptr(), dc.D, DegreeClasses.GEMM_ROWS, dc.tiles.data_ptr(),
+                                  dc.ntiles.data_ptr()))
+        check(lib.gnx_class_tiles(h, dc.cls_ptr.data_ptr(), dc.D, DegreeClasses.WGRAD_ROWS, dc.chunks.data_ptr(),
+                                  dc.nchunks.data_ptr()))
+        return dc
 
 
 def check_range(device: torch.device) -> None:
@@ -83,7 +129,7 @@ def pack_graph(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], batc
     N, E = int(num_nodes), int(edge_index.size(1))
     i32 = dict(dtype=torch.int32, device=dev)
     g = GraphPack()
-    g.N, g.E, g.device, g._scalers = N, E, dev, {}
+    g.N, g.E, g.device, g._scalers, g._classes = N, E, dev, {}, None
     g.rowptr = torch.empty(N + 1, **i32)
     g.colptr = torch.empty(N + 1, **i32)
     g.perm = torch.empty(E, **i32)
@@ -187,6 +233,61 @@ def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor]
     return out
 
 
+GSeg = Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor, int]  # (A view, rowscale|None, B of class 0, stride)
+
+
+def gemm_grouped(segs: Sequence[GSeg], out: torch.Tensor, dc: DegreeClasses, *, bias: Optional[torch.Tensor] = None,
+                 mask: Optional[torch.Tensor] = None, relu: bool = False, b_trans: bool = True) -> torch.Tensor:
+    """gemm() over the degree-class tiles of ``dc``: A rows gathered / out rows scattered through ``dc.dperm``; segment
+    s reads its weight at ``B_s + class * stride_s`` elements (stride 0 = the same weight for every class)."""
+    M, N = out.shape
+    if M == 0:
+        return out
+    cptr, ldc = _mat(out, "out")
+    arr = (GemmSeg * len(segs))()
+    strides = (C.c_int64 * len(segs))()
+    for i, (a, rs, b, stride) in enumerate(segs):
+        ap, lda = _mat(a, f"A[{i}]")
+        bp, ldb = _mat(b, f"B[{i}]")
+        arr[i].a, arr[i].lda, arr[i].rowscale = ap, lda, _ptr(rs)
+        arr[i].b, arr[i].ldb, arr[i].k = bp, ldb, a.size(1)
+        strides[i] = stride
+    flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_B_TRANS if b_trans else 0)
+    mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
+    check(_lib.load().gnx_gemm_grouped(handle(out.device), len(segs), arr, strides, M, N, _ptr(bias), mp, ldm, cptr,
+                                       ldc, flags, dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(),
+                                       dc.max_tiles))
+    return out
+
+
+def gemm_wgrad_grouped(dC: torch.Tensor, A: torch.Tensor, dW_cls: torch.Tensor, dc: DegreeClasses) -> None:
+    """dW_cls[c] (fp32[D, N, K], contiguous) += sum over rows of class c of dC[row]^T A[row]."""
+    M, N = dC.shape
+    if M == 0:
+        return
+    xp, ldx = _mat(dC, "dC")
+    ap, lda = _mat(A, "A")
+    K = A.size(1)
+    if dW_cls.shape != (dc.D, N, K) or not dW_cls.is_contiguous():
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"dW_cls must be contiguous [{dc.D},{N},{K}], got {tuple(dW_cls.shape)}")
+    check(_lib.load().gnx_gemm_wgrad_grouped(handle(dC.device), xp, ldx, ap, lda, M, N, K, dW_cls.data_ptr(), K, N * K,
+                                             dc.dperm.data_ptr(), dc.chunks.data_ptr(), dc.nchunks.data_ptr(),
+                                             dc.max_chunks))
+
+
+def pna_weff(W: torch.Tensor, F: int, D: int, avg_deg_log: float) -> torch.Tensor:
+    """Weff fp32[D, F, 4F] from post_nns[t][0].weight ([F, 13F])."""
+    wp, ldw = _mat(W, "W")
+    out = torch.empty(D, F, 4 * F, dtype=torch.float32, device=W.device)
+    check(_lib.load().gnx_pna_weff(handle(W.device), wp, ldw, F, D, float(avg_deg_log), out.data_ptr()))
+    return out
+
+
+def pna_weff_bwd(dWeff: torch.Tensor, F: int, D: int, avg_deg_log: float, dW: torch.Tensor) -> None:
+    wp, ldw = _mat(dW, "dW")
+    check(_lib.load().gnx_pna_weff_bwd(handle(dW.device), dWeff.data_ptr(), F, D, float(avg_deg_log), wp, ldw))
+
+
 _SIDE_STREAMS = {}
 _SIDE_ENABLED = False
 _SIDE_PENDING = set()
@@ -207,28 +308,47 @@ def join_side_stream(device: torch.device) -> None:
         _SIDE_PENDING.discard(idx)
 
 
-def gemm_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale: Optional[torch.Tensor] = None,
-               dbias: Optional[torch.Tensor] = None) -> None:
-    """dW[N,K] += dC[M,N]^T @ (rowscale * A[M,K]);  dbias[N] += column sums of dC."""
-    M, N = dC.shape
-    if M == 0:
-        return
-    if _SIDE_ENABLED and dC.is_cuda:
-        idx = dC.device.index
+def _run_on_side(ref: torch.Tensor, tensors, fn) -> None:
+    """Run ``fn`` (weight-gradient launches) on the side stream when enabled, else inline.  ``tensors`` are the device
+    buffers the launches read or write that could be freed before the side stream has run."""
+    if _SIDE_ENABLED and ref.is_cuda:
+        idx = ref.device.index
         side = _SIDE_STREAMS.get(idx)
         if side is None:
             side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
         main = torch.cuda.current_stream(idx)
         if main != side:
             side.wait_stream(main)  # operands were produced on the main stream
-            for t in (dC, A, rowscale):
+            for t in tensors:
                 if t is not None:
-                    t.record_stream(side)  # keep the allocator from recycling them under the side kernel
+                    t.record_stream(side)  # keep the allocator from recycling them under the side kernels
             _SIDE_PENDING.add(idx)
             with torch.cuda.stream(side):
-                _gemm_wgrad_launch(dC, A, dW, rowscale, dbias)
+                fn()
             return
-    _gemm_wgrad_launch(dC, A, dW, rowscale, dbias)
+    fn()
+
+
+def gemm_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale: Optional[torch.Tensor] = None,
+               dbias: Optional[torch.Tensor] = None) -> None:
+    """dW[N,K] += dC[M,N]^T @ (rowscale * A[M,K]);  dbias[N] += column sums of dC."""
+    if dC.size(0) == 0:
+        return
+    _run_on_side(dC, (dC, A, rowscale), lambda: _gemm_wgrad_launch(dC, A, dW, rowscale, dbias))
+
+
+def pna_post0_wgrad_classes(g: torch.Tensor, A: torch.Tensor, dc: "DegreeClasses", F: int, avg_deg_log: float,
+                            dW: torch.Tensor) -> None:
+    """dW[:, F:13F] += the three A-blocks of post-layer 0's weight gradient, through per-degree-class partial sums."""
+    if g.size(0) == 0:
+        return
+    dWeff = torch.zeros(dc.D, F, 4 * F, dtype=torch.float32, device=g.device)
+
+    def run():
+        gemm_wgrad_grouped(g, A, dWeff, dc)
+        pna_weff_bwd(dWeff, F, dc.D, avg_deg_log, dW)
+
+    _run_on_side(g, (g, A, dWeff), run)
 
 
 def _gemm_wgrad_launch(dC, A, dW, rowscale, dbias) -> None:

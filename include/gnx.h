@@ -138,6 +138,38 @@ int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t 
 int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
                        const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias);
 
+/* ---- in-degree classes: PNA post-layer 0 with one effective weight per degree ------------------------------- */
+/* amp/att of [3P] DegreeScalerAggregation depend on the in-degree d only, so
+ *     [x | A | amp*A | att*A] W^T  =  x W0^T + A (W1 + amp(d) W2 + att(d) W3)^T  =  x W0^T + A Weff(d)^T
+ * with rows grouped by d: 26 N F^2 -> 10 N F^2 FLOPs for the widest product of the layer (ref: train/models.py:445-457).
+ * gnx_degree_max: max in-degree (synchronises; the host needs D = max+1 to size buffers; D <= 64 for grouping).
+ * gnx_degree_classes: dperm int32[N] = node ids stably sorted by in-degree, cls_ptr int32[D+1] = class boundaries.
+ * gnx_class_tiles: tile_info int32[3*(N/tile_rows + D)] = (first position in dperm, #rows, class) per tile, tiles
+ * never straddle classes; ntiles int32[1] (device) = number of tiles. */
+int32_t gnx_degree_max(gnx_handle* h, const int32_t* rowptr, int64_t N, int32_t* max_degree_host);
+size_t gnx_degree_classes_workspace_bytes(int64_t N, int32_t D);
+int32_t gnx_degree_classes(gnx_handle* h, const int32_t* rowptr, int64_t N, int32_t D, int32_t* dperm,
+                           int32_t* cls_ptr, void* ws, size_t ws_bytes);
+int32_t gnx_class_tiles(gnx_handle* h, const int32_t* cls_ptr, int32_t D, int32_t tile_rows, int32_t* tile_info,
+                        int32_t* ntiles);
+/* gnx_gemm over class tiles: workgroup t handles rows row_index[tile_info[3t] .. +tile_info[3t+1]) (gathered A rows,
+ * scattered C rows) and reads segment s's B at b + class * cls_strides[s] (cls_strides: HOST int64[nseg], 0 = shared).
+ * Launches max_tiles workgroups; those >= *ntiles exit. */
+int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides, int64_t M,
+                         int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc,
+                         int32_t flags, const int32_t* row_index, const int32_t* tile_info, const int32_t* ntiles,
+                         int64_t max_tiles);
+/* per-class weight gradient: dW_cls[c] (stride dw_cls_stride) += sum over the rows of class c of dC[row]^T A[row]. */
+int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M,
+                               int32_t N, int32_t K, float* dW_cls, int64_t lddw, int64_t dw_cls_stride,
+                               const int32_t* row_index, const int32_t* chunk_info, const int32_t* nchunks,
+                               int64_t max_chunks);
+/* Weff[d][o][j] = W[o][F+j] + amp(d) W[o][5F+j] + att(d) W[o][9F+j]  (W = post_nns[t][0].weight [F,13F], ld ldw);
+ * gnx_pna_weff_bwd: dW[:,F:5F] += sum_d dWeff[d]; dW[:,5F:9F] += sum_d amp(d) dWeff[d]; dW[:,9F:13F] += sum_d att(d).. */
+int32_t gnx_pna_weff(gnx_handle* h, const float* W, int64_t ldw, int32_t F, int32_t D, float avg_deg_log, float* Weff);
+int32_t gnx_pna_weff_bwd(gnx_handle* h, const float* dWeff, int32_t F, int32_t D, float avg_deg_log, float* dW,
+                         int64_t lddw);
+
 /* ---- PNA message assembly (first pre-layer folded to node level) ------------------------------------------- */
 /* h1[p,:] = relu(P[dst[p],:] + Q[src[p],:] + Te[code[p],:])  for CSR position p;  width = H.
  * ([3P] PNAConv.message: Linear(3F->F) on cat([x_i, x_j, e]) == W_i x_i + W_j x_j + (W_e e + b), then ReLU.) */

@@ -212,3 +212,30 @@ def test_training_step_and_optimizer_contract(gpu_device):
         losses.append(float(loss))
     assert set(model.logged_metrics) >= {"train_huber", "train_mape"}
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_degree_class_path_matches_segment_path(gpu_device):
+    """A/B inside the HIP path: per-degree effective weights vs the 4-segment 13F-wide product (same model, batch)."""
+    from gnnepcsaft_amd import functional as Fn
+    from gnnepcsaft_amd.data import calc_deg, synthetic_batch
+    from gnnepcsaft_amd.train.models import create_model
+    cfg = _cfg(hidden_dim=64, towers=2, propagation_depth=2)
+    batch = synthetic_batch(64, 5)
+    deg = calc_deg(batch)
+    b = batch.to("cuda:0")
+    torch.manual_seed(0)
+    model = create_model(cfg, deg).to("cuda:0")
+    outs = []
+    for enabled in (True, False):
+        Fn.set_degree_classes(enabled)
+        try:
+            model.zero_grad()
+            b._gnx_pack = None
+            loss = model.training_step(b, 0)
+            loss.backward()
+            outs.append((loss.detach().clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()))
+        finally:
+            Fn.set_degree_classes(True)
+    assert rel_err(outs[0][0], outs[1][0]) <= 1e-5
+    num = float((outs[0][1] - outs[1][1]).norm())
+    assert num <= 2e-3 * float(outs[1][1].norm()), num

@@ -415,3 +415,75 @@ def test_huber_ape(gpu_device, count):
     loss.backward()
     assert rel_err(loss, ref) <= TOL and rel_err(both[1], O.mape(p.detach(), t)) <= TOL
     assert rel_err(pn.grad, p.grad) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# in-degree classes: PNA post-layer 0 with one effective weight per degree
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,E", [(1, 0), (300, 0), (777, 2000), (70000, 140000)])
+def test_degree_classes_bit_exact(gpu_device, N, E):
+    from gnnepcsaft_amd.ops import DegreeClasses
+    rng = np.random.default_rng(N + E)
+    ei = _graph(rng, N, E)
+    g = _pack(ei, None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    deg = np.bincount(ei[1].numpy(), minlength=N)
+    assert dc is not None and dc.D == int(deg.max()) + 1
+    assert np.array_equal(dc.dperm.cpu().numpy()[:N], np.argsort(deg, kind="stable"))
+    cls_ptr = np.concatenate([[0], np.cumsum(np.bincount(deg, minlength=dc.D))])
+    assert np.array_equal(dc.cls_ptr.cpu().numpy(), cls_ptr)
+    for rows, info, cnt in ((DegreeClasses.GEMM_ROWS, dc.tiles, dc.ntiles), (DegreeClasses.WGRAD_ROWS, dc.chunks, dc.nchunks)):
+        want = []
+        for c in range(dc.D):
+            for r in range(cls_ptr[c], cls_ptr[c + 1], rows):
+                want.append((r, min(rows, cls_ptr[c + 1] - r), c))
+        n = int(cnt)
+        assert n == len(want) and n <= info.numel() // 3
+        assert np.array_equal(info.cpu().numpy()[:3 * n].reshape(n, 3), np.array(want, dtype=np.int64).reshape(n, 3))
+
+
+def test_degree_classes_fallback_above_64(gpu_device):
+    ei = torch.stack([torch.arange(1, 101), torch.zeros(100, dtype=torch.long)])  # one hub of in-degree 100
+    g = _pack(ei, None, None, 101, None, gpu_device)
+    assert g.degree_classes() is None
+
+
+def test_pna_post0_degree_classes_equal_scaled_segments(gpu_device):
+    """x W0^T + A Weff(d)^T (grouped by in-degree) == the 13F-wide [x | A | amp*A | att*A] product, forward, input
+    gradient and weight gradient."""
+    from gnnepcsaft_amd import ops
+    rng = np.random.default_rng(21)
+    N, E, F = 3000, 7000, 32
+    ei = _graph(rng, N, E)
+    g = _pack(ei, None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    avg = 1.137
+    amp, att = g.degree_scalers(avg)
+    torch.manual_seed(5)
+    x, A = torch.randn(N, F), torch.randn(N, 4 * F)
+    W, b = torch.randn(F, 13 * F) / 8, torch.randn(F)
+    xd, Ad, Wd, bd = x.to(gpu_device), A.to(gpu_device), W.to(gpu_device), b.to(gpu_device)
+    cat = torch.cat([x, A, A * amp.cpu()[:, None], A * att.cpu()[:, None]], 1).double()
+    ref = (cat @ W.double().T + b.double()).relu()
+    weff = ops.pna_weff(Wd, F, dc.D, avg)
+    d = torch.arange(dc.D, dtype=torch.float32)
+    a_d, t_d = torch.log(d + 1) / avg, avg / torch.log(d.clamp(min=1) + 1)
+    weff_ref = W[None, :, F:5 * F] + a_d[:, None, None] * W[None, :, 5 * F:9 * F] + t_d[:, None, None] * W[None, :, 9 * F:]
+    assert rel_err(weff, weff_ref) <= 1e-6
+    z = torch.full((N, F), float("nan"), device=gpu_device)
+    ops.gemm_grouped([(xd, None, Wd[:, 0:F], 0), (Ad, None, weff[0], 4 * F * F)], z, dc, bias=bd, relu=True)
+    assert rel_err(z, ref) <= TOL
+    # input gradient dA = g Weff(d)
+    gr = torch.randn(N, F)
+    grd = gr.to(gpu_device)
+    ref_dA = gr.double() @ W[:, F:5 * F].double() + (gr * amp.cpu()[:, None]).double() @ W[:, 5 * F:9 * F].double() + \
+        (gr * att.cpu()[:, None]).double() @ W[:, 9 * F:].double()
+    dA = torch.full((N, 4 * F), float("nan"), device=gpu_device)
+    ops.gemm_grouped([(grd, None, weff[0], 4 * F * F)], dA, dc, b_trans=False)
+    assert rel_err(dA, ref_dA) <= TOL
+    # weight gradient of the three A blocks
+    dW = torch.zeros(F, 13 * F, device=gpu_device)
+    ops.pna_post0_wgrad_classes(grd, Ad, dc, F, avg, dW)
+    ref_dW = gr.double().T @ cat
+    assert rel_err(dW[:, F:], ref_dW[:, F:]) <= TOL
+    assert float(dW[:, :F].abs().max()) == 0.0
