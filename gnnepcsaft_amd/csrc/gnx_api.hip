@@ -23,6 +23,10 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
   GNX_HIP(hipSetDevice(device));
   gnx_handle* h = new gnx_handle();
   h->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+  }
   hipError_t e = hipMalloc(&h->d_flag, 256);
   if (e == hipSuccess) e = hipMalloc(&h->d_scratch, 4096);
   if (e == hipSuccess) e = hipMemset(h->d_flag, 0, 256);

@@ -11,6 +11,7 @@
 
 struct gnx_handle {
   int device = 0;
+  int num_cus = 0;
   hipStream_t stream = nullptr;
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;

@@ -1,19 +1,30 @@
 // Dense feature x weight contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
 //
-// Shapes on this path are tall-skinny: M = #edges or #nodes (1e5..1e6), N = 32..512, K = 32..13*F.
-// Tile: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).
-// Operands are staged global -> registers -> LDS (one LDS buffer; the next K-tile's global loads are issued before the
-// MFMAs of the current one and written to LDS after them), several workgroups per CU hide the two barriers per step.
+// Shapes on this path are tall-skinny: M = #edges or #nodes (1e5..1e6), N = 32..512, K = 32..13*F.  Three kernels:
+//   k_gemm       tiled 128 x 128 x 32, multi-segment (K-concatenated operands with per-row scale), optional row
+//                gather/scatter over degree-class tiles with per-class weights.
+//   k_gemm_ws    weights-stationary persistent kernel for ONE segment with K, N <= 128 (the most frequent shape):
+//                the weight image stays in LDS for the workgroup's lifetime, 64-row A tiles stream through a double
+//                buffer, one barrier per tile.
+//   k_gemm_wgrad dW += dC^T (rs * A): contraction over the rows, split over M, fp32 atomics.
+//
+// Lesson baked into the structure (measured, tools/gemm_diag.py + the ISA): any runtime-conditional global load in the
+// epilogue ("if (mask) v *= mask[...]", "if (accumulate) v += C[...]") makes hipcc put `s_waitcnt vmcnt(0)` in front of
+// EVERY store (3 per store in the first version of this file), serialising the 64 stores of a thread and draining the
+// next tile's prefetch.  The epilogue kind is therefore a template parameter, its loads are issued unconditionally
+// (clamped addresses) in one batch before they are used, and there are no loads between stores.
 //
 // LDS images:
-//   "row-k" image  T[row][k]  (A always; B when the weight is [n][k], i.e. NT): row stride 36 floats.  A lane (i = l&31,
-//        h = l>>5) fetches k = 8*kk + 4*h .. +3 with ONE ds_read_b128 and feeds element t to MFMA step t, i.e. MFMA step
-//        (kk,t) contracts k in {8kk+t, 8kk+4+t}: the k order inside a tile is permuted identically for A and B, which only
-//        reorders an exact-fp32 sum.  36 = 4*9 (9 odd) makes the 16 lanes of every ds_read_b128 group hit 16 distinct
-//        16-byte slots (MI355X_MICROARCH.md, LDS table).
-//   "k-row" image  T[k][col]  (B when the weight is [k][n], i.e. NN; both operands of the TN weight gradient):
+//   "row-k" image  T[row][k]  (A always; B when the weight is [n][k], i.e. NT): row stride 36 (tiled) / 132 (ws) floats,
+//        i.e. an odd number of 16-B slots.  A lane (i = l&31, h = l>>5) fetches k = 8*kk + 4*h .. +3 with ONE ds_read_b128
+//        and feeds element t to MFMA step t, i.e. MFMA step (kk,t) contracts k in {8kk+t, 8kk+4+t}: the k order inside
+//        a tile is permuted identically for A and B, which only reorders an exact-fp32 sum; the odd slot stride makes
+//        the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots (MI355X_MICROARCH.md, LDS table).
+//   "k-row" image  T[k][col]  (B when the weight is [k][n], i.e. NN; both operands of the weight gradient):
 //        row stride 128 floats, read with ds_read_b32 (32 consecutive columns per half-wave: conflict-free).
 #include "gnx_common.hpp"
+
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -21,6 +32,8 @@
 #define LDK 36    // row stride of the row-k image
 #define LDN 128   // row stride of the k-row image
 #define MAX_SEGS 4
+
+enum { EPI_PLAIN = 0, EPI_ACCUM = 1, EPI_MASK = 2 };
 
 struct seg_dev {
   const float* a;
@@ -45,7 +58,6 @@ struct gemm_args {
   float* C;
   int64_t ldc;
   int relu;
-  int accumulate;
   // grouped mode (degree classes): workgroup b handles rows row_index[tile_info[3b] .. +tile_info[3b+1]) with the
   // class-tile_info[3b+2] weights; workgroups >= *ntiles exit.  NULL tile_info = plain row tiles.
   const int* row_index;
@@ -67,10 +79,38 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int valid) {
   return v;
 }
 
-template <bool B_TRANS>
+// Epilogue of one 32x32 accumulator tile (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// rows[r] = global row of accumulator register r (-1 = padding); every lane of a half-wave shares it.
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const f32x16& acc, const int (&rows)[16], int gc, int N, float bv,
+                                              int relu, const float* __restrict__ mask, int64_t ldmask,
+                                              float* __restrict__ C, int64_t ldc) {
+  const bool col_ok = gc < N;
+  const int gcc = col_ok ? gc : 0;
+  float extra[16];
+  if constexpr (EPI != EPI_PLAIN) {
+    // one batch of unconditional loads (clamped rows), one wait, then the stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t gr = rows[r] < 0 ? 0 : rows[r];
+      extra[r] = (EPI == EPI_MASK) ? mask[gr * ldmask + gcc] : C[gr * ldc + gcc];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bv;
+    if constexpr (EPI == EPI_ACCUM) v += extra[r];
+    v = relu ? fmaxf(v, 0.f) : v;
+    if constexpr (EPI == EPI_MASK) v = (extra[r] > 0.f) ? v : 0.f;
+    if (col_ok && rows[r] >= 0) C[(int64_t)rows[r] * ldc + gc] = v;
+  }
+}
+
+template <bool B_TRANS, int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[B_TRANS ? BN * LDK : BK * LDN];
+  __shared__ int rid[BM];  // global row of every tile row (-1 = padding)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,7 +118,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
-  __shared__ int rid[BM];  // global row of every tile row (-1 = padding)
   int cls = 0;
   if (g.tile_info != nullptr) {
     if ((int)blockIdx.x >= g.ntiles[0]) return;
@@ -217,29 +256,230 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
     }
   }
 
-  // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < 2; ++mi) {
+    int rows[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[r] = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      int gc = n0 + wn * 64 + ni * 32 + li;
-      if (gc >= g.N) continue;
-      float bv = g.bias ? g.bias[gc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int64_t gr = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-        if (gr < 0) continue;
-        float v = acc[mi][ni][r] + bv;
-        float* cp = g.C + gr * g.ldc + gc;
-        if (g.accumulate) v += *cp;
-        if (g.relu) v = fmaxf(v, 0.f);
-        if (g.mask) v = (g.mask[gr * g.ldmask + gc] > 0.f) ? v : 0.f;
-        *cp = v;
-      }
+      const int gc = n0 + wn * 64 + ni * 32 + li;
+      const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+      epilogue_tile<EPI>(acc[mi][ni], rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
     }
+  }
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weights-stationary persistent GEMM: ONE segment, K <= 128, N <= 128, M = #nodes or #edges.
+//   LDS: B image [128][132] (NT) or [128][128] (NN) + 2 x A image [64][132]  = 135 KB (dynamic), 1 workgroup / CU.
+//   wave w: rows (w>>1)*32..+32, columns (w&1)*64..+64  (2 MFMA 32x32 tiles, 32 accumulators).
+// One workgroup per CU keeps the whole weight image in LDS and streams 64-row A tiles through a double buffer: the next
+// tile's global loads and the previous tile's stores are in flight while the MFMAs of the current tile run, with ONE
+// barrier per tile and none inside the K loop.
+// ---------------------------------------------------------------------------------------------------------------
+#define WS_BM 64
+#define WS_LD 132  // 33 x 16 B: odd -> the 16 lanes of every ds_read_b128 group hit distinct 16-B slots
+
+struct ws_args {
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  int64_t M;
+  int N, K;
+  const float* bias;
+  const float* mask;
+  int64_t ldmask;
+  float* C;
+  int64_t ldc;
+  int relu;
+  int ntiles;
+};
+
+template <bool B_TRANS, int EPI>
+__global__ void __launch_bounds__(256, 1) k_gemm_ws(ws_args g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Bs = lds;
+  float* As = lds + 128 * WS_LD;  // two buffers of WS_BM * WS_LD
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int kgroups = (g.K + 7) >> 3;
+
+  // ---- weight image, once per workgroup (zero-filled to 128 x 128); addresses clamped, values selected
+  {
+    const int r = tid >> 5, c4 = (tid & 31) * 4;  // 8 rows per pass, 16 passes
+    const int rmax = B_TRANS ? g.N : g.K, cmax = B_TRANS ? g.K : g.N;
+    const bool c_ok = c4 < cmax;
+    const int cc = c_ok ? c4 : 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int rr = r + 8 * i;
+      const bool ok = c_ok && rr < rmax;
+      f32x4 v = *reinterpret_cast<const f32x4*>(g.B + (int64_t)(rr < rmax ? rr : 0) * g.ldb + cc);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      v = ok ? v : z;
+      *reinterpret_cast<f32x4*>(&Bs[rr * (B_TRANS ? WS_LD : 128) + c4]) = v;
+    }
+  }
+
+  // ---- A tile loader: 32 lanes cover one 512-B row, 8 rows per pass, 8 passes; clamped addresses, no branches
+  const int ar = tid >> 5, ak = (tid & 31) * 4;
+  const bool ak_ok = ak < g.K;
+  const int akc = ak_ok ? ak : 0;
+  f32x4 ra[8];
+  auto load_a = [&](int tile) {
+    const int64_t m0 = (int64_t)tile * WS_BM;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t gm = m0 + ar + 8 * i;
+      const bool ok = ak_ok && gm < g.M;
+      f32x4 v = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[i] = ok ? v : z;
+    }
+  };
+  auto store_a = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&buf[(ar + 8 * i) * WS_LD + ak]) = ra[i];
+  };
+
+  float bv[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int gc = wc + ni * 32 + li;
+    bv[ni] = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+  }
+
+  int tile = blockIdx.x;  // grid <= ntiles
+  int cur = 0;
+  load_a(tile);
+  store_a(As);
+  __syncthreads();
+
+  while (tile < g.ntiles) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < g.ntiles;
+    if (has_next) load_a(next);  // wave-uniform branch; loads stay in flight during the MFMAs below
+    const int64_t m0 = (int64_t)tile * WS_BM;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    const float* Ab = As + cur * (WS_BM * WS_LD);
+    for (int kk = 0; kk < kgroups; ++kk) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(&Ab[(wr + li) * WS_LD + kk * 8 + 4 * lh]);
+      f32x4 b[2];
+      if (B_TRANS) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          b[ni] = *reinterpret_cast<const f32x4*>(&Bs[(wc + ni * 32 + li) * WS_LD + kk * 8 + 4 * lh]);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float* p = &Bs[(kk * 8 + 4 * lh) * 128 + wc + ni * 32 + li];
+          b[ni].x = p[0];
+          b[ni].y = p[128];
+          b[ni].z = p[256];
+          b[ni].w = p[384];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[ni][t], acc[ni], 0, 0, 0);
+    }
+
+    // epilogue (stores stay in flight under the next tile's MFMAs)
+    int rows[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t gr = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      rows[r] = gr < g.M ? (int)gr : -1;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      epilogue_tile<EPI>(acc[ni], rows, wc + ni * 32 + li, g.N, bv[ni], g.relu, g.mask, g.ldmask, g.C, g.ldc);
+
+    if (has_next) store_a(As + (cur ^ 1) * (WS_BM * WS_LD));
+    __syncthreads();
+    cur ^= 1;
+    tile = next;
+  }
+}
+
+template <bool BT, int EPI>
+static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws<BT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_ws<BT, EPI>), dim3(grid), dim3(256), lds_bytes, h->stream, g);
+  return hipGetLastError();
+}
+
+static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, int32_t N, const float* bias,
+                              const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
+  ws_args g;
+  g.A = s.a;
+  g.lda = s.lda;
+  g.B = s.b;
+  g.ldb = s.ldb;
+  g.M = M;
+  g.N = N;
+  g.K = s.k;
+  g.bias = bias;
+  g.mask = mask;
+  g.ldmask = ldmask;
+  g.C = C;
+  g.ldc = ldc;
+  g.relu = (flags & GNX_GEMM_RELU) ? 1 : 0;
+  g.ntiles = (int)gnx_cdiv(M, WS_BM);
+  const bool bt = (flags & GNX_GEMM_B_TRANS) != 0;
+  const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
+  const size_t lds_bytes = sizeof(float) * (128 * WS_LD + 2 * WS_BM * WS_LD);
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  const int grid = g.ntiles < cus ? g.ntiles : cus;
+  gnx_prof_scope prof(h, GNX_K_GEMM);
+  hipError_t e;
+  if (bt)
+    e = epi == EPI_MASK    ? ws_launch_one<true, EPI_MASK>(h, g, grid, lds_bytes)
+        : epi == EPI_ACCUM ? ws_launch_one<true, EPI_ACCUM>(h, g, grid, lds_bytes)
+                           : ws_launch_one<true, EPI_PLAIN>(h, g, grid, lds_bytes);
+  else
+    e = epi == EPI_MASK    ? ws_launch_one<false, EPI_MASK>(h, g, grid, lds_bytes)
+        : epi == EPI_ACCUM ? ws_launch_one<false, EPI_ACCUM>(h, g, grid, lds_bytes)
+                           : ws_launch_one<false, EPI_PLAIN>(h, g, grid, lds_bytes);
+  if (e != hipSuccess) {
+    gnx_set_error("gnx_gemm (weights-stationary): %s", hipGetErrorString(e));
+    return GNX_E_HIP;
+  }
+  return GNX_OK;
+}
+
+// eligibility of the weights-stationary path (everything else goes to the tiled kernel)
+static bool gemm_ws_eligible(int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N, const float* mask,
+                             int32_t flags) {
+  if (nseg != 1 || M < 8192) return false;
+  const gnx_gemm_seg& s = segs[0];
+  if (s.rowscale != nullptr || s.k > 128 || s.k < 32 || N > 128 || N < 32) return false;
+  if ((s.k % 4) != 0 || (N % 4) != 0) return false;
+  if (!aligned16(s.a) || (s.lda % 4) != 0 || !aligned16(s.b) || (s.ldb % 4) != 0) return false;
+  if (mask != nullptr && (flags & GNX_GEMM_ACCUMULATE)) return false;
+  const char* e = getenv("GNX_GEMM_WS");
+  if (e && atoi(e) == 0) return false;
+  return true;
+}
 
 static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                            int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
@@ -249,16 +489,23 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   GNX_CHECK_ARG(nseg >= 1 && nseg <= MAX_SEGS, "gnx_gemm: nseg=%d not in [1,%d]", nseg, MAX_SEGS);
   GNX_CHECK_ARG(M >= 0 && N > 0 && ldc >= N, "gnx_gemm: bad shape M=%lld N=%d ldc=%lld", (long long)M, N, (long long)ldc);
   GNX_CHECK_ARG(!((flags & GNX_GEMM_RELU) && (flags & GNX_GEMM_ACCUMULATE)), "gnx_gemm: relu+accumulate rejected");
+  GNX_CHECK_ARG(!(mask && (flags & GNX_GEMM_ACCUMULATE)), "gnx_gemm: mask+accumulate rejected");
   GNX_CHECK_ARG(mask == nullptr || ldmask >= N, "gnx_gemm: ldmask < N");
   if (M == 0) return GNX_OK;
   const bool bt = (flags & GNX_GEMM_B_TRANS) != 0;
-  gemm_args g;
-  for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   for (int s = 0; s < nseg; ++s) {
     const gnx_gemm_seg& in = segs[s];
     GNX_CHECK_ARG(in.a && in.b && in.k > 0, "gnx_gemm: segment %d: NULL operand or k<=0", s);
     GNX_CHECK_ARG(in.lda >= in.k, "gnx_gemm: segment %d: lda < k", s);
     GNX_CHECK_ARG(bt ? in.ldb >= in.k : in.ldb >= N, "gnx_gemm: segment %d: ldb too small", s);
+  }
+  if (tile_info == nullptr && gemm_ws_eligible(nseg, segs, M, N, mask, flags))
+    return gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
+
+  gemm_args g;
+  for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < nseg; ++s) {
+    const gnx_gemm_seg& in = segs[s];
     seg_dev d;
     d.a = in.a;
     d.rs = in.rowscale;
@@ -280,16 +527,27 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   g.C = C;
   g.ldc = ldc;
   g.relu = (flags & GNX_GEMM_RELU) ? 1 : 0;
-  g.accumulate = (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0;
   g.row_index = row_index;
   g.tile_info = tile_info;
   g.ntiles = ntiles;
+  const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM);
-  if (bt)
-    hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, h->stream, g);
-  else
-    hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, h->stream, g);
+  if (bt) {
+    if (epi == EPI_MASK)
+      hipLaunchKernelGGL((k_gemm<true, EPI_MASK>), grid, dim3(256), 0, h->stream, g);
+    else if (epi == EPI_ACCUM)
+      hipLaunchKernelGGL((k_gemm<true, EPI_ACCUM>), grid, dim3(256), 0, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm<true, EPI_PLAIN>), grid, dim3(256), 0, h->stream, g);
+  } else {
+    if (epi == EPI_MASK)
+      hipLaunchKernelGGL((k_gemm<false, EPI_MASK>), grid, dim3(256), 0, h->stream, g);
+    else if (epi == EPI_ACCUM)
+      hipLaunchKernelGGL((k_gemm<false, EPI_ACCUM>), grid, dim3(256), 0, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm<false, EPI_PLAIN>), grid, dim3(256), 0, h->stream, g);
+  }
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

@@ -1,0 +1,50 @@
+"""GPU parity of the weights-stationary persistent GEMM (k_gemm_ws: one segment, K,N <= 128, M >= 8192) against fp64
+torch, all epilogue variants, both weight layouts, ragged M / K / N; and against the tiled kernel (GNX_GEMM_WS=0)."""
+import os
+
+import pytest
+import torch
+
+from tests.parity_util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 128, 128), (20001, 128, 128), (81920, 128, 128), (9000, 64, 96), (8200, 36, 32),
+                                   (163840, 128, 128), (10000, 128, 100)])
+@pytest.mark.parametrize("b_trans", [True, False])
+def test_gemm_ws_variants(gpu_device, M, N, K, b_trans):
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K)
+    w = torch.randn(N, K) if b_trans else torch.randn(K, N)
+    b = torch.randn(N)
+    mask = torch.randn(M, N)
+    c0 = torch.randn(M, N)
+    ad, wd, bd = a.to(gpu_device), w.to(gpu_device), b.to(gpu_device)
+    prod = a.double() @ (w.double().T if b_trans else w.double())
+    out = torch.full((M, N), float("nan"), device=gpu_device)
+    ops.gemm([(ad, None, wd)], out, bias=bd, relu=True, b_trans=b_trans)
+    assert rel_err(out, (prod + b.double()).relu()) <= TOL
+    out = torch.full((M, N), float("nan"), device=gpu_device)
+    ops.gemm([(ad, None, wd)], out, b_trans=b_trans, mask=mask.to(gpu_device))
+    assert rel_err(out, prod * (mask > 0)) <= TOL
+    out = c0.clone().to(gpu_device)
+    ops.gemm([(ad, None, wd)], out, b_trans=b_trans, accumulate=True, bias=bd)
+    assert rel_err(out, c0.double() + prod + b.double()) <= TOL
+
+
+def test_gemm_ws_strided_views_and_guard_rows(gpu_device):
+    """Tower-style column slices (lda = ldc = H > K) and no write outside the output view."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(3)
+    M, H, F = 12345, 256, 64
+    x = torch.randn(M, H)
+    w = torch.randn(F, 3 * F)
+    xd, wd = x.to(gpu_device), w.to(gpu_device)
+    out = torch.zeros(M, H, device=gpu_device)
+    ops.gemm([(xd[:, F:2 * F], None, wd[:, F:2 * F])], out[:, 2 * F:3 * F])
+    ref = x[:, F:2 * F].double() @ w[:, F:2 * F].double().T
+    assert rel_err(out[:, 2 * F:3 * F], ref) <= TOL
+    assert float(out[:, :2 * F].abs().max()) == 0.0 and float(out[:, 3 * F:].abs().max()) == 0.0
