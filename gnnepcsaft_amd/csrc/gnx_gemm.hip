@@ -275,7 +275,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---------------------------------------------------------------------------------------------------------------
 // Weights-stationary persistent GEMM: ONE segment, K <= 128, N <= 128, M = #nodes or #edges.
 //   LDS: B image [128][132] (NT) or [128][128] (NN) + 2 x A image [64][132]  = 135 KB (dynamic), 1 workgroup / CU.
-//   wave w: rows (w>>1)*32..+32, columns (w&1)*64..+64  (2 MFMA 32x32 tiles, 32 accumulators).
+//   512 threads: wave w owns the 32x32 MFMA tile at rows (w>>2)*32, columns (w&3)*32 (16 accumulators); two waves per
+//   SIMD cover each other's LDS-read latency and epilogue.
 // One workgroup per CU keeps the whole weight image in LDS and streams 64-row A tiles through a double buffer: the next
 // tile's global loads and the previous tile's stores are in flight while the MFMAs of the current tile run, with ONE
 // barrier per tile and none inside the K loop.
@@ -299,26 +300,50 @@ struct ws_args {
   int ntiles;
 };
 
+// full-tile epilogue of one 32x32 accumulator tile: no row checks, one base pointer, constant row strides
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile_full(const f32x16& acc, int64_t row0, int gc, int N, float bv, int relu,
+                                                   const float* __restrict__ mask, int64_t ldmask,
+                                                   float* __restrict__ C, int64_t ldc) {
+  if (gc >= N) return;
+  float* cp = C + row0 * ldc + gc;
+  float extra[16];
+  if constexpr (EPI != EPI_PLAIN) {
+    const float* ep = (EPI == EPI_MASK) ? mask + row0 * ldmask + gc : cp;
+    const int64_t lde = (EPI == EPI_MASK) ? ldmask : ldc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) extra[r] = ep[((r & 3) + 8 * (r >> 2)) * lde];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bv;
+    if constexpr (EPI == EPI_ACCUM) v += extra[r];
+    v = relu ? fmaxf(v, 0.f) : v;
+    if constexpr (EPI == EPI_MASK) v = (extra[r] > 0.f) ? v : 0.f;
+    cp[((r & 3) + 8 * (r >> 2)) * ldc] = v;
+  }
+}
+
 template <bool B_TRANS, int EPI>
-__global__ void __launch_bounds__(256, 1) k_gemm_ws(ws_args g) {
+__global__ void __launch_bounds__(512, 1) k_gemm_ws(ws_args g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Bs = lds;
   float* As = lds + 128 * WS_LD;  // two buffers of WS_BM * WS_LD
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+  const int lane = tid & 63, wave = tid >> 6;       // 8 waves: two per SIMD hide each other's LDS / epilogue latency
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;  // one 32x32 MFMA tile per wave
   const int li = lane & 31, lh = lane >> 5;
   const int kgroups = (g.K + 7) >> 3;
 
   // ---- weight image, once per workgroup (zero-filled to 128 x 128); addresses clamped, values selected
   {
-    const int r = tid >> 5, c4 = (tid & 31) * 4;  // 8 rows per pass, 16 passes
+    const int r = tid >> 5, c4 = (tid & 31) * 4;  // 16 rows per pass, 8 passes
     const int rmax = B_TRANS ? g.N : g.K, cmax = B_TRANS ? g.K : g.N;
     const bool c_ok = c4 < cmax;
     const int cc = c_ok ? c4 : 0;
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int rr = r + 8 * i;
+    for (int i = 0; i < 8; ++i) {
+      const int rr = r + 16 * i;
       const bool ok = c_ok && rr < rmax;
       f32x4 v = *reinterpret_cast<const f32x4*>(g.B + (int64_t)(rr < rmax ? rr : 0) * g.ldb + cc);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -327,16 +352,16 @@ __global__ void __launch_bounds__(256, 1) k_gemm_ws(ws_args g) {
     }
   }
 
-  // ---- A tile loader: 32 lanes cover one 512-B row, 8 rows per pass, 8 passes; clamped addresses, no branches
+  // ---- A tile loader: 32 lanes cover one 512-B row, 16 rows per pass, 4 passes; clamped addresses, no branches
   const int ar = tid >> 5, ak = (tid & 31) * 4;
   const bool ak_ok = ak < g.K;
   const int akc = ak_ok ? ak : 0;
-  f32x4 ra[8];
+  f32x4 ra[4];
   auto load_a = [&](int tile) {
     const int64_t m0 = (int64_t)tile * WS_BM;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t gm = m0 + ar + 8 * i;
+    for (int i = 0; i < 4; ++i) {
+      const int64_t gm = m0 + ar + 16 * i;
       const bool ok = ak_ok && gm < g.M;
       f32x4 v = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -345,15 +370,11 @@ __global__ void __launch_bounds__(256, 1) k_gemm_ws(ws_args g) {
   };
   auto store_a = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&buf[(ar + 8 * i) * WS_LD + ak]) = ra[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&buf[(ar + 16 * i) * WS_LD + ak]) = ra[i];
   };
 
-  float bv[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int gc = wc + ni * 32 + li;
-    bv[ni] = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
-  }
+  const int gc = wc + li;
+  const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
 
   int tile = blockIdx.x;  // grid <= ntiles
   int cur = 0;
@@ -367,46 +388,52 @@ __global__ void __launch_bounds__(256, 1) k_gemm_ws(ws_args g) {
     if (has_next) load_a(next);  // wave-uniform branch; loads stay in flight during the MFMAs below
     const int64_t m0 = (int64_t)tile * WS_BM;
 
-    f32x16 acc[2];
+    f32x16 acc;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-    const float* Ab = As + cur * (WS_BM * WS_LD);
-    for (int kk = 0; kk < kgroups; ++kk) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(&Ab[(wr + li) * WS_LD + kk * 8 + 4 * lh]);
-      f32x4 b[2];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* Ap = As + cur * (WS_BM * WS_LD) + (wr + li) * WS_LD + 4 * lh;
+    const float* Bp = B_TRANS ? Bs + (wc + li) * WS_LD + 4 * lh : Bs + (4 * lh) * 128 + wc + li;
+    auto frag_b = [&](int kk) {
+      f32x4 b;
       if (B_TRANS) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          b[ni] = *reinterpret_cast<const f32x4*>(&Bs[(wc + ni * 32 + li) * WS_LD + kk * 8 + 4 * lh]);
+        b = *reinterpret_cast<const f32x4*>(Bp + kk * 8);
       } else {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const float* p = &Bs[(kk * 8 + 4 * lh) * 128 + wc + ni * 32 + li];
-          b[ni].x = p[0];
-          b[ni].y = p[128];
-          b[ni].z = p[256];
-          b[ni].w = p[384];
-        }
+        const float* p = Bp + kk * 8 * 128;
+        b.x = p[0];
+        b.y = p[128];
+        b.z = p[256];
+        b.w = p[384];
       }
+      return b;
+    };
+    // software-pipelined fragment reads: the reads of group kk+1 are issued before the MFMAs of group kk
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap), b0 = frag_b(0);
+    for (int kk = 0; kk < kgroups; kk += 2) {
+      const int k1 = (kk + 1 < kgroups) ? kk + 1 : kk;
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + k1 * 8), b1 = frag_b(k1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+      const int k2 = (kk + 2 < kgroups) ? kk + 2 : kk;
+      a0 = *reinterpret_cast<const f32x4*>(Ap + k2 * 8);
+      b0 = frag_b(k2);
+      if (kk + 1 < kgroups) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[ni][t], acc[ni], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc, 0, 0, 0);
+      }
     }
 
     // epilogue (stores stay in flight under the next tile's MFMAs)
-    int rows[16];
+    if (m0 + WS_BM <= g.M) {
+      epilogue_tile_full<EPI>(acc, m0 + wr + 4 * lh, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+    } else {
+      int rows[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t gr = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      rows[r] = gr < g.M ? (int)gr : -1;
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gr = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        rows[r] = gr < g.M ? (int)gr : -1;
+      }
+      epilogue_tile<EPI>(acc, rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
     }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-      epilogue_tile<EPI>(acc[ni], rows, wc + ni * 32 + li, g.N, bv[ni], g.relu, g.mask, g.ldmask, g.C, g.ldc);
 
     if (has_next) store_a(As + (cur ^ 1) * (WS_BM * WS_LD));
     __syncthreads();
@@ -424,7 +451,7 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm_ws<BT, EPI>), dim3(grid), dim3(256), lds_bytes, h->stream, g);
+  hipLaunchKernelGGL((k_gemm_ws<BT, EPI>), dim3(grid), dim3(512), lds_bytes, h->stream, g);
   return hipGetLastError();
 }
 
