@@ -106,7 +106,12 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const int (&row
   }
 }
 
-template <bool B_TRANS, int EPI>
+__device__ __constant__ float c_one = 1.0f;  // row scale of segments that have none (pointer-select, no branch)
+
+// VEC = every operand is 16-B aligned with leading dimensions / k / class strides multiples of 4 (always true for the
+// model's shapes): loads are unconditional float4 from clamped addresses + a select, so all 8 loads of a K-tile are in
+// flight together.  VEC = false keeps the generic element-wise path (odd shapes; correctness only).
+template <bool B_TRANS, int EPI, bool VEC>
 __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[B_TRANS ? BN * LDK : BK * LDN];
@@ -150,9 +155,45 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   int grow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) grow[i] = rid[lr + 32 * i];
+  int okmask = 0;   // VEC: validity bits of ra[0..3] (bits 0-3) and rb[0..3] (bits 4-7) of the tile in flight
+  float rsv[4] = {1.f, 1.f, 1.f, 1.f};
 
   auto load_tile = [&](const seg_dev& s, int k0) {
     const float* sb = s.b + (int64_t)cls * s.cls_stride;
+    if constexpr (VEC) {
+      // raw loads only: the select / row scale are applied in store_tile, so nothing consumes the loaded registers
+      // before the MFMAs of the current tile have been issued (a select here makes hipcc wait for the loads at once)
+      const int kcol = k0 + lk;
+      const bool k_ok = kcol < s.k;
+      const int kc = k_ok ? kcol : 0;
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = grow[i] >= 0 ? grow[i] : 0;
+        ra[i] = *reinterpret_cast<const f32x4*>(s.a + row * s.lda + kc);
+        rsv[i] = *(s.rs != nullptr ? s.rs + row : &c_one);
+        okmask |= (k_ok && grow[i] >= 0) ? (1 << i) : 0;
+      }
+      if (B_TRANS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gn = n0 + lr + 32 * i;
+          rb[i] = *reinterpret_cast<const f32x4*>(sb + (int64_t)(gn < g.N ? gn : 0) * s.ldb + kc);
+          okmask |= (k_ok && gn < g.N) ? (16 << i) : 0;
+        }
+      } else {
+        const int nn = n0 + bc;
+        const bool n_ok = nn < g.N;
+        const int nc = n_ok ? nn : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kr = k0 + br + 8 * i;
+          rb[i] = *reinterpret_cast<const f32x4*>(sb + (int64_t)(kr < s.k ? kr : 0) * s.ldb + nc);
+          okmask |= (n_ok && kr < s.k) ? (16 << i) : 0;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int64_t gm = grow[i];
@@ -189,6 +230,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm(gemm_args g) {
   };
 
   auto store_tile = [&]() {
+    if constexpr (VEC) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = ra[i];
+        v.x *= rsv[i];
+        v.y *= rsv[i];
+        v.z *= rsv[i];
+        v.w *= rsv[i];
+        ra[i] = ((okmask >> i) & 1) ? v : z;
+        rb[i] = ((okmask >> (4 + i)) & 1) ? rb[i] : z;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int r = lr + 32 * i;
@@ -357,20 +411,22 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws(ws_args g) {
   const bool ak_ok = ak < g.K;
   const int akc = ak_ok ? ak : 0;
   f32x4 ra[4];
+  int okmask = 0;  // validity of ra[] of the tile in flight; applied at LDS-store time so the loads stay in flight
   auto load_a = [&](int tile) {
     const int64_t m0 = (int64_t)tile * WS_BM;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t gm = m0 + ar + 16 * i;
-      const bool ok = ak_ok && gm < g.M;
-      f32x4 v = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[i] = ok ? v : z;
+      ra[i] = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
+      okmask |= (ak_ok && gm < g.M) ? (1 << i) : 0;
     }
   };
   auto store_a = [&](float* buf) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&buf[(ar + 16 * i) * WS_LD + ak]) = ra[i];
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(&buf[(ar + 16 * i) * WS_LD + ak]) = ((okmask >> i) & 1) ? ra[i] : z;
   };
 
   const int gc = wc + li;
@@ -560,21 +616,36 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM);
+  bool vec = true;
+  {
+    const char* e = getenv("GNX_GEMM_VEC");
+    if (e && atoi(e) == 0) vec = false;
+  }
+  for (int s = 0; s < nseg; ++s)
+    vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
+#define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
+  do {                                                                                    \
+    if (vec)                                                                              \
+      hipLaunchKernelGGL((k_gemm<BT, EPI, true>), grid, dim3(256), 0, h->stream, g);      \
+    else                                                                                  \
+      hipLaunchKernelGGL((k_gemm<BT, EPI, false>), grid, dim3(256), 0, h->stream, g);     \
+  } while (0)
   if (bt) {
     if (epi == EPI_MASK)
-      hipLaunchKernelGGL((k_gemm<true, EPI_MASK>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(true, EPI_MASK);
     else if (epi == EPI_ACCUM)
-      hipLaunchKernelGGL((k_gemm<true, EPI_ACCUM>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(true, EPI_ACCUM);
     else
-      hipLaunchKernelGGL((k_gemm<true, EPI_PLAIN>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(true, EPI_PLAIN);
   } else {
     if (epi == EPI_MASK)
-      hipLaunchKernelGGL((k_gemm<false, EPI_MASK>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(false, EPI_MASK);
     else if (epi == EPI_ACCUM)
-      hipLaunchKernelGGL((k_gemm<false, EPI_ACCUM>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(false, EPI_ACCUM);
     else
-      hipLaunchKernelGGL((k_gemm<false, EPI_PLAIN>), grid, dim3(256), 0, h->stream, g);
+      GNX_LAUNCH_GEMM(false, EPI_PLAIN);
   }
+#undef GNX_LAUNCH_GEMM
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
@@ -617,6 +688,7 @@ struct wgrad_args {
   int64_t dw_cls_stride;
 };
 
+template <bool VEC, bool GROUPED>
 __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
   __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
@@ -631,7 +703,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   int64_t r_end = r_begin + g.rows_per_block;
   if (r_end > g.M) r_end = g.M;
   float* dW = g.dW;
-  if (g.chunk_info != nullptr) {
+  if constexpr (GROUPED) {
     if ((int)blockIdx.x >= g.nchunks[0]) return;
     r_begin = g.chunk_info[3 * blockIdx.x];
     r_end = r_begin + g.chunk_info[3 * blockIdx.x + 1];
@@ -650,13 +722,39 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   const int br = tid >> 5;
   const int bc = (tid & 31) * 4;
   f32x4 rx[4], ry[4];
+  int okmask = 0;
+  float rsv[4] = {1.f, 1.f, 1.f, 1.f};
 
   auto load_tile = [&](int64_t r0) {
+    if constexpr (VEC) {
+      // raw loads; select / row scale deferred to the LDS store (see k_gemm)
+      const int xn = n0 + bc, yk = c0 + bc;
+      const bool x_ok = xn < g.N, y_ok = yk < g.K;
+      const int xc = x_ok ? xn : 0, yc = y_ok ? yk : 0;
+      int64_t rowi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t pos = r0 + br + 8 * i;
+        const int64_t pc = pos < r_end ? pos : r_begin;  // clamped (r_begin < r_end here)
+        rowi[i] = GROUPED ? (int64_t)g.row_index[pc] : pc;
+      }
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool rv = r0 + br + 8 * i < r_end;
+        rx[i] = *reinterpret_cast<const f32x4*>(g.X + rowi[i] * g.ldx + xc);
+        ry[i] = *reinterpret_cast<const f32x4*>(g.Y + rowi[i] * g.ldy + yc);
+        rsv[i] = *(g.rs != nullptr ? g.rs + rowi[i] : &c_one);
+        okmask |= (rv && x_ok) ? (1 << i) : 0;
+        okmask |= (rv && y_ok) ? (16 << i) : 0;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int64_t gm = r0 + br + 8 * i;
       bool rv = gm < r_end;
-      if (g.row_index != nullptr && rv) gm = g.row_index[gm];
+      if (GROUPED && rv) gm = g.row_index[gm];
       int nv = rv ? g.N - (n0 + bc) : 0;
       rx[i] = ld4(g.X + gm * g.ldx + n0 + bc, g.vec_x, nv);
       int kv = rv ? g.K - (c0 + bc) : 0;
@@ -676,6 +774,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   if (r0 < r_end) load_tile(r0);
   while (r0 < r_end) {
     __syncthreads();
+    if constexpr (VEC) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = ry[i];
+        v.x *= rsv[i];
+        v.y *= rsv[i];
+        v.z *= rsv[i];
+        v.w *= rsv[i];
+        rx[i] = ((okmask >> i) & 1) ? rx[i] : z;
+        ry[i] = ((okmask >> (4 + i)) & 1) ? v : z;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int kr = br + 8 * i;
@@ -758,7 +869,12 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.vec_y = aligned16(A) && (lda % 4 == 0);
   int64_t tiles = gnx_cdiv(N, BN) * gnx_cdiv(K, BN);
   // aim for ~512 workgroups; at least 128 rows each (4 K-steps) so the atomic flush stays amortised
-  int64_t chunks = gnx_cdiv(512, tiles);
+  int64_t target_wgs = 512;
+  {
+    const char* e = getenv("GNX_WGRAD_WGS");
+    if (e && atoi(e) > 0) target_wgs = atoi(e);
+  }
+  int64_t chunks = gnx_cdiv(target_wgs, tiles);
   int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
   if (rows < 128) rows = 128;
   g.rows_per_block = rows;
@@ -768,7 +884,22 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.dw_cls_stride = dw_cls_stride;
   dim3 grid((unsigned)(chunk_info ? max_chunks : gnx_cdiv(M, rows)), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
-  hipLaunchKernelGGL(k_gemm_wgrad, grid, dim3(256), 0, h->stream, g);
+  bool vec = g.vec_x && g.vec_y && (N % 4 == 0) && (K % 4 == 0);
+  {
+    const char* e = getenv("GNX_WGRAD_VEC");
+    if (e && atoi(e) == 0) vec = false;
+  }
+  if (chunk_info) {
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_wgrad<true, true>), grid, dim3(256), 0, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm_wgrad<false, true>), grid, dim3(256), 0, h->stream, g);
+  } else {
+    if (vec)
+      hipLaunchKernelGGL((k_gemm_wgrad<true, false>), grid, dim3(256), 0, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm_wgrad<false, false>), grid, dim3(256), 0, h->stream, g);
+  }
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
