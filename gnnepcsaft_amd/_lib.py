@@ -47,7 +47,8 @@ SIGNATURES = {
     "gnx_graph_ptr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _sz]),
     "gnx_degree_scalers": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "gnx_embed_sum_fwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _vp, _i32, _vp]),
-    "gnx_embed_sum_bwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _i32, _vp, _i32, _vp]),
+    "gnx_table_scatter_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "gnx_embed_sum_bwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _i32, _vp, _i32, _vp, _vp, _sz]),
     "gnx_check_range": (_i32, [_vp]),
     "gnx_gemm": (_i32, [_vp, _i32, C.POINTER(GemmSeg), _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
     "gnx_gemm_wgrad": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "gnx_pna_weff": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "gnx_pna_weff_bwd": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _i64]),
     "gnx_edge_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz]),
     "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_pna_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),

@@ -11,7 +11,7 @@
 #include <cmath>
 
 int32_t gnx_code_scatter_add(gnx_handle* h, const int32_t* code, int64_t E, int R, const float* g, int H,
-                             float* dtable);
+                             float* dtable, void* ws, size_t ws_bytes);
 
 template <int VEC>
 struct vec_t;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) k_edge_combine_bwd(const float* __restric
 
 extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int32_t* rowptr, const int32_t* colptr,
                                         const int32_t* cpos, const int32_t* code, int64_t N, int64_t E, int32_t H,
-                                        int32_t R, float* dP, float* dQ, float* dTe) {
+                                        int32_t R, float* dP, float* dQ, float* dTe, void* ws, size_t ws_bytes) {
   GNX_CHECK_ARG(h && H > 0 && N >= 0 && E >= 0, "gnx_edge_combine_bwd: bad argument");
   if (N == 0) return GNX_OK;
   GNX_CHECK_ARG(rowptr && colptr && dP && dQ && (E == 0 || (g && cpos)), "gnx_edge_combine_bwd: NULL argument");
@@ -321,7 +321,7 @@ extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int
   GNX_LAUNCH_CHECK();
   if (dTe != nullptr && E > 0) {
     GNX_CHECK_ARG(code && R > 0, "gnx_edge_combine_bwd: code/R missing for dTe");
-    return gnx_code_scatter_add(h, code, E, R, g, H, dTe);
+    return gnx_code_scatter_add(h, code, E, R, g, H, dTe, ws, ws_bytes);
   }
   return GNX_OK;
 }

@@ -73,7 +73,8 @@ extern "C" int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t 
 template <typename IdxT, int VEC>
 __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restrict__ idx, int64_t N, int K, offs_t offs,
                                                            int R, const float* __restrict__ dout, int H, int CW,
-                                                           int64_t rows_per_block, float* __restrict__ dtable) {
+                                                           int64_t rows_per_block, float* __restrict__ dtable,
+                                                           float* __restrict__ part) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
   for (int i = tid; i < R * CW; i += 256) lds[i] = 0.f;
@@ -122,6 +123,13 @@ __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restric
     }
   }
   __syncthreads();
+  if (part != nullptr) {
+    // two-stage reduction: every block stores its private table; k_table_reduce folds them.  (Hundreds of blocks
+    // atomically adding into the same few KB serialise at the memory-side atomic units: 100+ us for a 60-row table.)
+    float* dst = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (int64_t)R * CW;
+    for (int i = tid; i < R * CW; i += 256) dst[i] = lds[i];
+    return;
+  }
   for (int i = tid; i < R * CW; i += 256) {
     int r = i / CW, cc = blockIdx.y * CW + (i % CW);
     float v = lds[i];
@@ -129,42 +137,97 @@ __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restric
   }
 }
 
+// dtable[r, col] += sum over chunks of part[chunk][slab][r][c]; grid = (elements / 256, chunk groups); each thread folds
+// its chunk group in order and issues one atomic (<= 16 per address in total).
+__global__ void __launch_bounds__(256) k_table_reduce(const float* __restrict__ part, int nchunks, int slabs, int R,
+                                                      int CW, int H, int chunks_per_group, float* __restrict__ dtable) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // element of the [R, slabs*CW] padded table
+  const int W = slabs * CW;
+  if (e >= (int64_t)R * W) return;
+  const int r = (int)(e / W), col = (int)(e % W);
+  if (col >= H) return;
+  const int slab = col / CW, c = col % CW;
+  int c0 = blockIdx.y * chunks_per_group, c1 = c0 + chunks_per_group;
+  if (c1 > nchunks) c1 = nchunks;
+  float acc = 0.f;
+  for (int ch = c0; ch < c1; ++ch) acc += part[(((int64_t)ch * slabs + slab) * R + r) * CW + c];
+  if (acc != 0.f) atomicAdd(&dtable[(int64_t)r * H + col], acc);
+}
+
+static void table_scatter_geometry(int64_t N, int R, int H, int* CW, int* slabs, int64_t* rows_per_block,
+                                   int64_t* chunks) {
+  int cw = 64;
+  while ((size_t)R * cw * sizeof(float) > 64 * 1024 && cw > 8) cw >>= 1;
+  *CW = cw;
+  *slabs = (int)gnx_cdiv(H, cw);
+  // ~768 blocks (3 per CU) in total; at least 256 rows each so the per-block table traffic stays a small fraction
+  int64_t rpb = gnx_cdiv(N, gnx_cdiv(768, *slabs));
+  if (rpb < 256) rpb = 256;
+  *rows_per_block = rpb;
+  *chunks = gnx_cdiv(N, rpb);
+}
+
+size_t gnx_table_scatter_ws_bytes(int64_t N, int R, int H) {
+  if (N <= 0) return 0;
+  int CW, slabs;
+  int64_t rpb, chunks;
+  table_scatter_geometry(N, R, H, &CW, &slabs, &rpb, &chunks);
+  return sizeof(float) * (size_t)chunks * slabs * R * CW;
+}
+
 template <typename IdxT>
 static int32_t launch_table_scatter_add(gnx_handle* h, const IdxT* idx, int64_t N, int K, const int32_t* offsets, int R,
-                                        const float* dout, int H, float* dtable) {
+                                        const float* dout, int H, float* dtable, void* ws, size_t ws_bytes) {
   offs_t o;
   for (int k = 0; k <= 17; ++k) o.o[k] = offsets[k <= K ? k : K];
-  int CW = 64;
-  while ((size_t)R * CW * sizeof(float) > 64 * 1024 && CW > 8) CW >>= 1;
+  int CW, slabs;
+  int64_t rows_per_block, chunks;
+  table_scatter_geometry(N, R, H, &CW, &slabs, &rows_per_block, &chunks);
   GNX_CHECK_ARG((size_t)R * CW * sizeof(float) <= 64 * 1024, "table scatter-add: %d rows do not fit the LDS tile", R);
-  int slabs = (int)gnx_cdiv(H, CW);
-  // ~768 blocks (3 per CU) in total; at least 256 rows each so the R x CW atomic flush stays a small fraction
-  int64_t rows_per_block = gnx_cdiv(N, gnx_cdiv(768, slabs));
-  if (rows_per_block < 256) rows_per_block = 256;
-  int64_t chunks = gnx_cdiv(N, rows_per_block);
+  float* part = nullptr;
+  if (ws != nullptr && chunks > 8) {
+    if (ws_bytes < gnx_table_scatter_ws_bytes(N, R, H)) {
+      gnx_set_error("table scatter-add: workspace %zu < %zu", ws_bytes, gnx_table_scatter_ws_bytes(N, R, H));
+      return GNX_E_WORKSPACE;
+    }
+    part = reinterpret_cast<float*>(ws);
+  }
   if (H % 4 == 0)
     hipLaunchKernelGGL((k_table_scatter_add<IdxT, 4>), dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
-                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
+                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable,
+                       part);
   else
     hipLaunchKernelGGL((k_table_scatter_add<IdxT, 1>), dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
-                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable);
+                       (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable,
+                       part);
   GNX_LAUNCH_CHECK();
+  if (part != nullptr) {
+    const int groups = (int)(chunks < 16 ? chunks : 16);
+    const int cpg = (int)gnx_cdiv(chunks, groups);
+    hipLaunchKernelGGL(k_table_reduce, dim3((unsigned)gnx_cdiv((int64_t)R * slabs * CW, 256), (unsigned)groups),
+                       dim3(256), 0, h->stream, part, (int)chunks, slabs, R, CW, H, cpg, dtable);
+    GNX_LAUNCH_CHECK();
+  }
   return GNX_OK;
 }
 
+extern "C" size_t gnx_table_scatter_workspace_bytes(int64_t rows, int32_t R, int32_t H) {
+  return gnx_table_scatter_ws_bytes(rows, R, H);
+}
+
 extern "C" int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
-                                     int32_t R, const float* dout, int32_t H, float* dtable) {
+                                     int32_t R, const float* dout, int32_t H, float* dtable, void* ws, size_t ws_bytes) {
   GNX_CHECK_ARG(h && offsets && dtable && K > 0 && K <= 16 && H > 0 && R > 0 && N >= 0, "gnx_embed_sum_bwd: bad argument");
   GNX_CHECK_ARG(N == 0 || (idx && dout), "gnx_embed_sum_bwd: NULL array with N>0");
   GNX_CHECK_ARG(offsets[K] == R, "gnx_embed_sum_bwd: offsets[K]=%d != R=%d", offsets[K], R);
   if (N == 0) return GNX_OK;
-  return launch_table_scatter_add<int64_t>(h, idx, N, K, offsets, R, dout, H, dtable);
+  return launch_table_scatter_add<int64_t>(h, idx, N, K, offsets, R, dout, H, dtable, ws, ws_bytes);
 }
 
 // used by gnx_edge_combine_bwd / gnx_gine_aggregate_bwd (int32 codes, one table)
 int32_t gnx_code_scatter_add(gnx_handle* h, const int32_t* code, int64_t E, int R, const float* g, int H,
-                             float* dtable) {
+                             float* dtable, void* ws, size_t ws_bytes) {
   if (E == 0) return GNX_OK;
   int32_t offs[2] = {0, R};
-  return launch_table_scatter_add<int32_t>(h, code, E, 1, offs, R, g, H, dtable);
+  return launch_table_scatter_add<int32_t>(h, code, E, 1, offs, R, g, H, dtable, ws, ws_bytes);
 }

@@ -564,6 +564,58 @@ static bool gemm_ws_eligible(int32_t nseg, const gnx_gemm_seg* segs, int64_t M, 
   return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M product (M <= 256: the 60-row bond-table chain  BondEmb -> edge_encoder -> pre-layer-0 slice and its
+// gradients).  The tiled kernel spends ~22 us of pure load/barrier latency on such a problem in ONE workgroup; here a
+// 16 x 16 output patch per 256-thread workgroup stages its A rows and B rows/columns in LDS once and every thread does
+// one K-long dot product: ~M/16 * N/16 workgroups in parallel, a few microseconds.  One segment, no row scale / mask.
+// ---------------------------------------------------------------------------------------------------------------
+#define SM_T 16
+#define SM_KC 128  // K chunk staged per pass
+
+template <bool B_TRANS>
+__global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A, int64_t lda,
+                                                     const float* __restrict__ B, int64_t ldb, int M, int N, int K,
+                                                     const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                                                     int relu, int accumulate) {
+  __shared__ float As[SM_T][SM_KC + 1];
+  __shared__ float Bs[SM_T][SM_KC + 1];  // Bs[n][k]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.x * SM_T, n0 = blockIdx.y * SM_T;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SM_KC) {
+    const int kc = (K - k0) < SM_KC ? (K - k0) : SM_KC;
+    // stage A[m0..+16][k0..+kc] : consecutive threads along k
+    for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+      const int r = i / SM_KC, k = i % SM_KC;
+      As[r][k] = (m0 + r < M && k < kc) ? A[(int64_t)(m0 + r) * lda + k0 + k] : 0.f;
+    }
+    if (B_TRANS) {  // B[n][k]
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int r = i / SM_KC, k = i % SM_KC;
+        Bs[r][k] = (n0 + r < N && k < kc) ? B[(int64_t)(n0 + r) * ldb + k0 + k] : 0.f;
+      }
+    } else {  // B[k][n] : consecutive threads along n
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int k = i / SM_T, r = i % SM_T;
+        Bs[r][k] = (n0 + r < N && k < kc) ? B[(int64_t)(k0 + k) * ldb + n0 + r] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < SM_KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);  // same k-ordered fmaf chain as the MFMA
+    __syncthreads();
+  }
+  const int gm = m0 + ty, gn = n0 + tx;
+  if (gm < M && gn < N) {
+    float v = acc + (bias != nullptr ? bias[gn] : 0.f);
+    float* cp = C + (int64_t)gm * ldc + gn;
+    if (accumulate) v += *cp;
+    *cp = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
 static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                            int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
                            int64_t ldc, int32_t flags, const int32_t* row_index, const int32_t* tile_info,
@@ -584,6 +636,19 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   }
   if (tile_info == nullptr && gemm_ws_eligible(nseg, segs, M, N, mask, flags))
     return gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
+  if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr) {
+    const gnx_gemm_seg& s0 = segs[0];
+    dim3 grid((unsigned)gnx_cdiv(M, SM_T), (unsigned)gnx_cdiv(N, SM_T));
+    gnx_prof_scope prof(h, GNX_K_GEMM);
+    if (bt)
+      hipLaunchKernelGGL(k_gemm_small<true>, grid, dim3(256), 0, h->stream, s0.a, s0.lda, s0.b, s0.ldb, (int)M, (int)N,
+                         (int)s0.k, bias, C, ldc, (flags & GNX_GEMM_RELU) ? 1 : 0, (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_gemm_small<false>, grid, dim3(256), 0, h->stream, s0.a, s0.lda, s0.b, s0.ldb, (int)M, (int)N,
+                         (int)s0.k, bias, C, ldc, (flags & GNX_GEMM_RELU) ? 1 : 0, (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0);
+    GNX_LAUNCH_CHECK();
+    return GNX_OK;
+  }
 
   gemm_args g;
   for (int s = 0; s < MAX_SEGS; ++s) g.seg[s] = seg_dev{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};

@@ -44,6 +44,112 @@ __global__ void __launch_bounds__(256) k_bn_partial(const float* __restrict__ x,
   }
 }
 
+
+// float4 variants (H % 4 == 0): block = 32 column-quads x 8 row lanes; grid.y covers 128 columns per block.
+__global__ void __launch_bounds__(256) k_bn_partial_v4(const float* __restrict__ x, int64_t M, int H,
+                                                       float* __restrict__ part) {
+  __shared__ f32x4 s1[8][32], s2[8][32];
+  const int cq = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.y * 128 + cq * 4;
+  int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+  int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  if (col < H) {
+    const f32x4 k = *reinterpret_cast<const f32x4*>(x + col);
+    for (int64_t r = r0 + ry; r < r1; r += 8) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + r * H + col);
+      v -= k;
+      a1 += v;
+      a2 += v * v;
+    }
+  }
+  s1[ry][cq] = a1;
+  s2[ry][cq] = a2;
+  __syncthreads();
+  if (ry == 0 && col < H) {
+    f32x4 t1 = s1[0][cq], t2 = s2[0][cq];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+      t1 += s1[l][cq];
+      t2 += s2[l][cq];
+    }
+    *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 0) * H + col) = t1;
+    *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 1) * H + col) = t2;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, int64_t M, int H,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, int relu,
+                                                           float* __restrict__ part) {
+  __shared__ f32x4 s1[8][32], s2[8][32];
+  const int cq = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.y * 128 + cq * 4;
+  int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+  int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  if (col < H) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
+    for (int64_t r = r0 + ry; r < r1; r += 8) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * H + col);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + col);
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * H + col);
+        g.x = yv.x > 0.f ? g.x : 0.f;
+        g.y = yv.y > 0.f ? g.y : 0.f;
+        g.z = yv.z > 0.f ? g.z : 0.f;
+        g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      a1 += g;
+      a2 += g * ((xv - mu) * rs);
+    }
+  }
+  s1[ry][cq] = a1;
+  s2[ry][cq] = a2;
+  __syncthreads();
+  if (ry == 0 && col < H) {
+    f32x4 t1 = s1[0][cq], t2 = s2[0][cq];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+      t1 += s1[l][cq];
+      t2 += s2[l][cq];
+    }
+    *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 0) * H + col) = t1;
+    *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 1) * H + col) = t2;
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_v(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ y, int64_t total, int H,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ coef, int relu,
+                                                        float* __restrict__ dx) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < total; i += stride) {
+    const int c = (int)(i % H);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + i);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+    if (relu) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i);
+      g.x = yv.x > 0.f ? g.x : 0.f;
+      g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f;
+      g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c), k1 = *reinterpret_cast<const f32x4*>(coef + H + c),
+                k2 = *reinterpret_cast<const f32x4*>(coef + 2 * H + c);
+    const f32x4 xh = (xv - mu) * rs;
+    *reinterpret_cast<f32x4*>(dx + i) = k0 * (g - k1 - xh * k2);
+  }
+}
+
 // Fold the per-chunk partials of 16 columns with 16 lanes per column (lane l takes chunks l, l+16, ... in order, then
 // the 16 lane sums are added in lane order): deterministic, ~chunks/16 dependent loads instead of `chunks`.
 // blockDim = 256 = 16 chunk-lanes (y) x 16 columns (x); returns the totals to the y == 0 threads.
@@ -148,8 +254,12 @@ extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, i
   int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
   gnx_prof_scope prof(h, GNX_K_BN_FWD);
   if (training) {
-    hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, x, M,
-                       (int)H, part);
+    if (H % 4 == 0)
+      hipLaunchKernelGGL(k_bn_partial_v4, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 128)), dim3(256), 0, h->stream, x,
+                         M, (int)H, part);
+    else
+      hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, x, M,
+                         (int)H, part);
     GNX_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)gnx_cdiv(H, 16)), dim3(256), 0, h->stream, x, part, chunks, M, (int)H,
@@ -246,17 +356,28 @@ extern "C" int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float
   float* part = coef + 4 * (size_t)H;
   int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
   gnx_prof_scope prof(h, GNX_K_BN_BWD);
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, dy, x,
-                     y, M, (int)H, save_mean, save_rstd, (int)relu, part);
+  if (H % 4 == 0)
+    hipLaunchKernelGGL(k_bn_bwd_partial_v4, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 128)), dim3(256), 0, h->stream,
+                       dy, x, y, M, (int)H, save_mean, save_rstd, (int)relu, part);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 64)), dim3(256), 0, h->stream, dy,
+                       x, y, M, (int)H, save_mean, save_rstd, (int)relu, part);
   GNX_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)gnx_cdiv(H, 16)), dim3(256), 0, h->stream, part, chunks, M, (int)H,
                      gamma, save_rstd, dgamma, dbeta, coef);
   GNX_LAUNCH_CHECK();
   int64_t total = M * H;
-  int64_t blocks = gnx_cdiv(total, 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, h->stream, dy, x, y, total, (int)H, save_mean,
-                     save_rstd, coef, (int)relu, dx);
+  if (H % 4 == 0) {
+    int64_t blocks = gnx_cdiv(total / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_bn_bwd_apply_v<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, dy, x, y, total, (int)H,
+                       save_mean, save_rstd, coef, (int)relu, dx);
+  } else {
+    int64_t blocks = gnx_cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, h->stream, dy, x, y, total, (int)H,
+                       save_mean, save_rstd, coef, (int)relu, dx);
+  }
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

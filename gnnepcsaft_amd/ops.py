@@ -193,8 +193,11 @@ def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor)
     idx = idx.contiguous()
     H = dout.size(1)
     dtable = torch.zeros(R, H, dtype=torch.float32, device=dout.device)
-    check(_lib.load().gnx_embed_sum_bwd(handle(dout.device), idx.data_ptr(), idx.size(0), K, _carr(list(offsets)), R,
-                                        dout.data_ptr(), H, dtable.data_ptr()))
+    lib = _lib.load()
+    nbytes = lib.gnx_table_scatter_workspace_bytes(idx.size(0), R, H)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dout.device)
+    check(lib.gnx_embed_sum_bwd(handle(dout.device), idx.data_ptr(), idx.size(0), K, _carr(list(offsets)), R,
+                                dout.data_ptr(), H, dtable.data_ptr(), ws.data_ptr(), nbytes))
     return dtable
 
 
@@ -381,9 +384,12 @@ def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tens
     dP = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
     dQ = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
     dTe = torch.zeros(R, H, dtype=torch.float32, device=gr.device)
-    check(_lib.load().gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
-                                           g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(),
-                                           dQ.data_ptr(), dTe.data_ptr()))
+    lib = _lib.load()
+    nbytes = lib.gnx_table_scatter_workspace_bytes(g.E, R, H)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=gr.device)
+    check(lib.gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
+                                   g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(), dQ.data_ptr(),
+                                   dTe.data_ptr(), ws.data_ptr(), nbytes))
     return dP, dQ, dTe
 
 

@@ -102,9 +102,12 @@ int32_t gnx_degree_scalers(gnx_handle* h, const int32_t* rowptr, int64_t N, floa
  * flag, reported by the next gnx_pack_* / gnx_check_range call. */
 int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
                           const float* table, int32_t H, float* out);
-/* dtable[R,H] += scatter-add of dout[N,H] (embedding_dense_backward); LDS-privatised, then one atomic per row/col. */
+/* dtable[R,H] += scatter-add of dout[N,H] (embedding_dense_backward): per-workgroup LDS tables (<= 256 rows), then a
+ * two-stage fold through the caller's workspace (gnx_table_scatter_workspace_bytes(N, R, H); ws may be NULL = direct
+ * atomics, slower: hundreds of workgroups adding into the same few KB serialise at the memory-side atomic units). */
+size_t gnx_table_scatter_workspace_bytes(int64_t rows, int32_t R, int32_t H);
 int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t K, const int32_t* offsets,
-                          int32_t R, const float* dout, int32_t H, float* dtable);
+                          int32_t R, const float* dout, int32_t H, float* dtable, void* ws, size_t ws_bytes);
 int32_t gnx_check_range(gnx_handle* h); /* sync; GNX_E_RANGE if any lazy check tripped since the last call */
 
 /* ---- dense contractions: fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 ------------------------------------ */
@@ -176,10 +179,11 @@ int32_t gnx_pna_weff_bwd(gnx_handle* h, const float* dWeff, int32_t F, int32_t D
 int32_t gnx_edge_combine_fwd(gnx_handle* h, const float* P, const float* Q, const float* Te, const int32_t* src,
                              const int32_t* dst, const int32_t* code, int64_t E, int32_t H, int32_t relu, float* h1);
 /* given g[E,H] (already masked by relu'):  dP[i,:] = sum_{p in row i} g[p,:] ;  dQ[j,:] = sum_{p in cpos(j)} g[p,:] ;
- * dTe[R,H] += scatter-add by code (LDS-privatised). dP/dQ are overwritten. */
+ * dTe[R,H] += scatter-add by code (LDS-privatised, ws = gnx_table_scatter_workspace_bytes(E, R, H) or NULL).
+ * dP/dQ are overwritten. */
 int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int32_t* rowptr, const int32_t* colptr,
                              const int32_t* cpos, const int32_t* code, int64_t N, int64_t E, int32_t H, int32_t R,
-                             float* dP, float* dQ, float* dTe);
+                             float* dP, float* dQ, float* dTe, void* ws, size_t ws_bytes);
 
 /* ---- the scatter-aggregate: PNA mean|min|max|std over target nodes  (HBM-bound; the roofline kernel) ------- */
 /* [3P] MultiAggregation([Mean,Min,Max,Std], mode='cat') as used by DegreeScalerAggregation
