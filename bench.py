@@ -93,6 +93,7 @@ def main():
     Fn.set_grad_in_place(True)  # weight-gradient kernels accumulate straight into the flat all-reduce buffer
     ops.set_wgrad_side_stream(not args.no_side_stream)  # wgrad kernels overlap the dgrad chain on a second stream
     Fn.set_degree_classes(not args.no_degree_classes)
+    ops.set_wgrad_batching(os.environ.get("GNX_WGRAD_BATCH", "1") != "0")
     b = batch_cpu.to(dev)
     N_nodes, E_edges = b.x.size(0), b.edge_index.size(1)
     H, T = cfg["hidden_dim"], cfg["towers"]

@@ -29,6 +29,12 @@ class GemmSeg(C.Structure):
                 ("ldb", C.c_int64), ("k", C.c_int32), ("_pad", C.c_int32)]
 
 
+class WgradProb(C.Structure):
+    _fields_ = [("dC", C.c_void_p), ("lddc", C.c_int64), ("A", C.c_void_p), ("lda", C.c_int64),
+                ("rowscale", C.c_void_p), ("dW", C.c_void_p), ("lddw", C.c_int64), ("dbias", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32)]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # every symbol include/gnx.h declares: name -> (restype, argtypes)
@@ -52,6 +58,7 @@ SIGNATURES = {
     "gnx_check_range": (_i32, [_vp]),
     "gnx_gemm": (_i32, [_vp, _i32, C.POINTER(GemmSeg), _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
     "gnx_gemm_wgrad": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "gnx_gemm_wgrad_batched": (_i32, [_vp, _i32, C.POINTER(WgradProb)]),
     "gnx_degree_max": (_i32, [_vp, _vp, _i64, C.POINTER(_i32)]),
     "gnx_degree_classes_workspace_bytes": (_sz, [_i64, _i32]),
     "gnx_degree_classes": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz]),

@@ -88,36 +88,44 @@ __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restric
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > N) r1 = N;
-  if (col < H) {
-    // two rows in flight per thread: the loop is latency-bound otherwise (few hundred rows per block)
-    for (int64_t n = r0 + rl; n < r1; n += 2 * RL) {
-      const int64_t n2 = n + RL;
-      const bool has2 = n2 < r1;
-      float g0[VEC], g1[VEC];
-      if constexpr (VEC == 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(dout + n * H + col);
-        g0[0] = v.x; g0[1] = v.y; g0[2] = v.z; g0[3] = v.w;
-        if (has2) {
-          f32x4 w = *reinterpret_cast<const f32x4*>(dout + n2 * H + col);
-          g1[0] = w.x; g1[1] = w.y; g1[2] = w.z; g1[3] = w.w;
+  if (col < H && r0 < r1) {
+    // four rows in flight per thread; every load is unconditional (clamped row) and issued before any use, so one
+    // round trip serves 4 rows x (1 gradient quad + 1 index) instead of a dependent chain per row
+    constexpr int UN = 4;
+    for (int64_t n = r0 + rl; n < r1; n += UN * RL) {
+      int64_t nn[UN];
+      bool ok[UN];
+      float g[UN][VEC];
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        const int64_t row = n + (int64_t)j * RL;
+        ok[j] = row < r1;
+        nn[j] = ok[j] ? row : r0;
+      }
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        if constexpr (VEC == 4) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(dout + nn[j] * H + col);
+          g[j][0] = v.x;
+          g[j][1] = v.y;
+          g[j][2] = v.z;
+          g[j][3] = v.w;
+        } else {
+          g[j][0] = dout[nn[j] * H + col];
         }
-      } else {
-        g0[0] = dout[n * H + col];
-        if (has2) g1[0] = dout[n2 * H + col];
       }
       for (int k = 0; k < K; ++k) {
         const int rows = offs.o[k + 1] - offs.o[k];
-        int64_t f0 = (int64_t)idx[n * K + k];
-        int64_t f1 = has2 ? (int64_t)idx[n2 * K + k] : -1;
-        if (f0 >= 0 && f0 < rows) {  // out-of-range indices were flagged in forward
-          float* d = &lds[(offs.o[k] + (int)f0) * CW + c];
+        int64_t f[UN];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) atomicAdd(d + v, g0[v]);
-        }
-        if (f1 >= 0 && f1 < rows) {
-          float* d = &lds[(offs.o[k] + (int)f1) * CW + c];
+        for (int j = 0; j < UN; ++j) f[j] = (int64_t)idx[nn[j] * K + k];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) atomicAdd(d + v, g1[v]);
+        for (int j = 0; j < UN; ++j) {
+          if (ok[j] && f[j] >= 0 && f[j] < rows) {  // out-of-range indices were flagged in forward
+            float* d = &lds[(offs.o[k] + (int)f[j]) * CW + c];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) atomicAdd(d + v, g[j][v]);
+          }
         }
       }
     }

@@ -754,26 +754,27 @@ struct wgrad_args {
 };
 
 template <bool VEC, bool GROUPED>
-__global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
-  __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
-  __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
+__device__ __forceinline__ void wgrad_body(const wgrad_args& g, const int bx, const int by, const int bz, float* Xs,
+                                           float* Ys) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * BN;  // dW row tile (output features)
-  const int c0 = blockIdx.z * BN;  // dW col tile (input features)
-  int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
+  const int n0 = by * BN;  // dW row tile (output features)
+  const int c0 = bz * BN;  // dW col tile (input features)
+  if (n0 >= g.N || c0 >= g.K) return;
+  int64_t r_begin = (int64_t)bx * g.rows_per_block;
   int64_t r_end = r_begin + g.rows_per_block;
   if (r_end > g.M) r_end = g.M;
   float* dW = g.dW;
   if constexpr (GROUPED) {
-    if ((int)blockIdx.x >= g.nchunks[0]) return;
-    r_begin = g.chunk_info[3 * blockIdx.x];
-    r_end = r_begin + g.chunk_info[3 * blockIdx.x + 1];
-    dW += (int64_t)g.chunk_info[3 * blockIdx.x + 2] * g.dw_cls_stride;
+    if (bx >= g.nchunks[0]) return;
+    r_begin = g.chunk_info[3 * bx];
+    r_end = r_begin + g.chunk_info[3 * bx + 1];
+    dW += (int64_t)g.chunk_info[3 * bx + 2] * g.dw_cls_stride;
   }
+  if (r_begin >= r_end) return;  // (workgroup-uniform) nothing to contribute: skip the zero-valued atomic flush
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -862,7 +863,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
     r0 += BK;
     if (r0 < r_end) load_tile(r0);
 
-    if (g.dbias != nullptr && blockIdx.z == 0 && tid < BN) {
+    if (g.dbias != nullptr && bz == 0 && tid < BN) {
 #pragma unroll 8
       for (int r = 0; r < BK; ++r) bsum += Xs[r * LDN + tid];
     }
@@ -908,7 +909,38 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
         atomicAdd(dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
       }
     }
-  if (g.dbias != nullptr && blockIdx.z == 0 && tid < BN && n0 + tid < g.N) atomicAdd(g.dbias + n0 + tid, bsum);
+  if (g.dbias != nullptr && bz == 0 && tid < BN && n0 + tid < g.N) atomicAdd(g.dbias + n0 + tid, bsum);
+}
+
+template <bool VEC, bool GROUPED>
+__global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
+  __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
+  __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
+  wgrad_body<VEC, GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, Xs, Ys);
+}
+
+// Several independent weight gradients in ONE launch (a layer's same-shaped dW = g^T a products): blockIdx.x =
+// problem * chunks + chunk.  With P problems sharing the grid every workgroup owns a P x longer row range, so the
+// per-problem atomic flush shrinks P x at equal parallelism (a lone 128x128 dW over 82k rows flushes 33 MB of fp32
+// atomics for 17 us of MFMA work).
+#define WGRAD_MAX_BATCH 8
+struct wgrad_batch_args {
+  wgrad_args p[WGRAD_MAX_BATCH];
+  int nprob;
+  int chunks;
+};
+
+__global__ void __launch_bounds__(256, 2) k_gemm_wgrad_batched(wgrad_batch_args b) {
+  __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
+  __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
+  const int prob = blockIdx.x / b.chunks;
+  const int chunk = blockIdx.x - prob * b.chunks;
+  // copy the selected descriptor (wave-uniform index) so the body sees scalars
+  wgrad_args g = b.p[0];
+#pragma unroll
+  for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
+    if (i == prob) g = b.p[i];
+  wgrad_body<true, false>(g, chunk, blockIdx.y, blockIdx.z, Xs, Ys);
 }
 
 static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
@@ -1041,6 +1073,60 @@ extern "C" int32_t gnx_pna_weff_bwd(gnx_handle* h, const float* dWeff, int32_t F
   int64_t n = (int64_t)F * 4 * F;
   hipLaunchKernelGGL(k_pna_weff_bwd, dim3((unsigned)gnx_cdiv(n, 256)), dim3(256), 0, h->stream, dWeff, (int)F, (int)D,
                      avg_deg_log, dW, lddw);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gnx_wgrad_prob* probs) {
+  GNX_CHECK_ARG(h && probs && nprob >= 1 && nprob <= WGRAD_MAX_BATCH, "gnx_gemm_wgrad_batched: nprob must be in [1,%d]",
+                WGRAD_MAX_BATCH);
+  wgrad_batch_args b;
+  int64_t maxM = 0;
+  int maxN = 0, maxK = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const gnx_wgrad_prob& q = probs[i];
+    GNX_CHECK_ARG(q.dC && q.A && q.dW && q.M >= 0 && q.N > 0 && q.K > 0 && q.lddc >= q.N && q.lda >= q.K && q.lddw >= q.K,
+                  "gnx_gemm_wgrad_batched: problem %d: bad argument", i);
+    const bool vec = aligned16(q.dC) && (q.lddc % 4 == 0) && aligned16(q.A) && (q.lda % 4 == 0) && (q.N % 4 == 0) &&
+                     (q.K % 4 == 0);
+    GNX_CHECK_ARG(vec, "gnx_gemm_wgrad_batched: problem %d is not 16-byte aligned / multiple-of-4 shaped", i);
+    wgrad_args g;
+    g.X = q.dC;
+    g.ldx = q.lddc;
+    g.Y = q.A;
+    g.ldy = q.lda;
+    g.rs = q.rowscale;
+    g.M = q.M;
+    g.N = q.N;
+    g.K = q.K;
+    g.dW = q.dW;
+    g.lddw = q.lddw;
+    g.dbias = q.dbias;
+    g.vec_x = g.vec_y = 1;
+    g.row_index = nullptr;
+    g.chunk_info = nullptr;
+    g.nchunks = nullptr;
+    g.dw_cls_stride = 0;
+    g.rows_per_block = 0;
+    b.p[i] = g;
+    if (q.M > maxM) maxM = q.M;
+    if (q.N > maxN) maxN = q.N;
+    if (q.K > maxK) maxK = q.K;
+  }
+  for (int i = nprob; i < WGRAD_MAX_BATCH; ++i) b.p[i] = b.p[0];
+  if (maxM == 0) return GNX_OK;
+  const int64_t tiles = gnx_cdiv(maxN, BN) * gnx_cdiv(maxK, BN);
+  int64_t chunks = gnx_cdiv(512, tiles * nprob);
+  if (chunks < 1) chunks = 1;
+  for (int i = 0; i < nprob; ++i) {
+    int64_t rows = gnx_cdiv(gnx_cdiv(b.p[i].M > 0 ? b.p[i].M : 1, chunks), BK) * BK;
+    b.p[i].rows_per_block = rows;  // chunks whose range starts beyond M do nothing
+  }
+  b.nprob = nprob;
+  b.chunks = (int)chunks;
+  dim3 grid((unsigned)(chunks * nprob), (unsigned)gnx_cdiv(maxN, BN), (unsigned)gnx_cdiv(maxK, BN));
+  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
+  hipLaunchKernelGGL(k_gemm_wgrad_batched, grid, dim3(256), 0, h->stream, b);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

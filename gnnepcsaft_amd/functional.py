@@ -95,7 +95,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm([(dy, None, weight)], _empty(x.size(0), x.size(1), x), b_trans=False)
-        ops.join_side_stream(dy.device)
+        ops.join_side_stream_at_end_of_backward()
         return dx, (None if sw is not None else dw), (None if (sb is not None or not ctx.has_bias) else db)
 
 
@@ -254,7 +254,7 @@ class PNAConvFn(torch.autograd.Function):
         sl = [slice(t * F, (t + 1) * F) for t in range(T)]
         dout = dout.contiguous()
         # lin
-        ops.gemm_wgrad(dout, zs[-1], d_lin_w, dbias=d_lin_b)
+        ops.queue_wgrad(dout, zs[-1], d_lin_w, dbias=d_lin_b)
         g = ops.gemm([(dout, None, lin_w)], _empty(N, H, x), b_trans=False)
         # post layers last..1 : dgrad masked by the relu'd input activation
         for i in range(post_layers - 1, 0, -1):
@@ -262,7 +262,7 @@ class PNAConvFn(torch.autograd.Function):
             gn = _empty(N, H, x)
             for t in range(T):
                 k = pidx(t, "post", i)
-                ops.gemm_wgrad(g[:, sl[t]], a_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
+                ops.queue_wgrad(g[:, sl[t]], a_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
                 ops.gemm([(g[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=a_prev[:, sl[t]])
             g = gn
         # post layer 0: 4-segment weight gradient, 3-segment dA
@@ -272,15 +272,15 @@ class PNAConvFn(torch.autograd.Function):
             Wp, dWp = params[k], grads[k]
             gt = g[:, sl[t]]
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
-            ops.gemm_wgrad(gt, x[:, sl[t]], dWp[:, 0:F], dbias=grads[k + 1])
+            ops.queue_wgrad(gt, x[:, sl[t]], dWp[:, 0:F], dbias=grads[k + 1])
             if ctx.dc is not None:
                 ops.pna_post0_wgrad_classes(gt, At, ctx.dc, F, ctx.cfg[4], dWp)
                 ops.gemm_grouped([(gt, None, ctx.weffs[t][0], 4 * F * F)], dA[:, t * 4 * F:(t + 1) * 4 * F], ctx.dc,
                                  b_trans=False)
             else:
-                ops.gemm_wgrad(gt, At, dWp[:, F:5 * F])
-                ops.gemm_wgrad(gt, At, dWp[:, 5 * F:9 * F], rowscale=amp)
-                ops.gemm_wgrad(gt, At, dWp[:, 9 * F:13 * F], rowscale=att)
+                ops.queue_wgrad(gt, At, dWp[:, F:5 * F])
+                ops.queue_wgrad(gt, At, dWp[:, 5 * F:9 * F], rowscale=amp)
+                ops.queue_wgrad(gt, At, dWp[:, 9 * F:13 * F], rowscale=att)
                 ops.gemm([(gt, None, Wp[:, F:5 * F]), (gt, amp, Wp[:, 5 * F:9 * F]), (gt, att, Wp[:, 9 * F:13 * F])],
                          dA[:, t * 4 * F:(t + 1) * 4 * F], b_trans=False)
         ge = ops.pna_aggregate_bwd(dA, hs[-1], A, pack, T, F)
@@ -289,7 +289,7 @@ class PNAConvFn(torch.autograd.Function):
             gn = _empty(E, H, x)
             for t in range(T):
                 k = pidx(t, "pre", i)
-                ops.gemm_wgrad(ge[:, sl[t]], h_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
+                ops.queue_wgrad(ge[:, sl[t]], h_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
                 ops.gemm([(ge[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=h_prev[:, sl[t]])
             ge = gn
         dP, dQ, dTe = ops.edge_combine_bwd(ge, pack, R)
@@ -300,15 +300,16 @@ class PNAConvFn(torch.autograd.Function):
             W0, dW0 = params[k0], grads[k0]
             kp = pidx(t, "post", 0)
             xt = x[:, sl[t]]
-            ops.gemm_wgrad(dP[:, sl[t]], xt, dW0[:, 0:F])
-            ops.gemm_wgrad(dQ[:, sl[t]], xt, dW0[:, F:2 * F])
-            ops.gemm_wgrad(dTe[:, sl[t]], EE, dW0[:, 2 * F:3 * F], dbias=grads[k0 + 1])
+            ops.queue_wgrad(dP[:, sl[t]], xt, dW0[:, 0:F])
+            ops.queue_wgrad(dQ[:, sl[t]], xt, dW0[:, F:2 * F])
+            ops.queue_wgrad(dTe[:, sl[t]], EE, dW0[:, 2 * F:3 * F], dbias=grads[k0 + 1])
             ops.gemm([(dTe[:, sl[t]], None, W0[:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
             ops.gemm([(g[:, sl[t]], None, params[kp][:, 0:F]), (dP[:, sl[t]], None, W0[:, 0:F]),
                       (dQ[:, sl[t]], None, W0[:, F:2 * F])], dx[:, sl[t]], b_trans=False)
-        ops.gemm_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
+        ops.queue_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
         dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
-        ops.join_side_stream(x.device)
+        ops.flush_wgrads()  # the layer's weight gradients in batched launches on the weight-gradient stream
+        ops.join_side_stream_at_end_of_backward()
         return (dx, dBE, None, None, *[None if sk is not None else g_ for g_, sk in zip(grads, sinks)])
 
 
@@ -352,6 +353,6 @@ class GINEConvFn(torch.autograd.Function):
         dx, dLe = ops.gine_aggregate_bwd(dagg, x, Le, pack, ctx.eps)
         ops.gemm_wgrad(dLe, BE, dlw, dbias=dlb)
         dBE = ops.gemm([(dLe, None, lin_w)], _empty(BE.size(0), BE.size(1), x), b_trans=False)
-        ops.join_side_stream(x.device)
+        ops.join_side_stream_at_end_of_backward()
         outs = [None if k is not None else g_ for g_, k in zip((dlw, dlb, dw0, db0, dw2, db2), sk)]
         return (dx, dBE, None, None, *outs)

@@ -303,6 +303,89 @@ def set_wgrad_side_stream(enabled: bool) -> None:
     _SIDE_ENABLED = bool(enabled)
 
 
+_JOIN_QUEUED = False
+
+
+def _join_all_side_streams() -> None:
+    global _JOIN_QUEUED
+    _JOIN_QUEUED = False
+    for idx in list(_SIDE_PENDING):
+        torch.cuda.current_stream(idx).wait_stream(_SIDE_STREAMS[idx])
+        _SIDE_PENDING.discard(idx)
+
+
+def join_side_stream_at_end_of_backward() -> None:
+    """Called from inside an autograd backward: the main stream waits for the weight-gradient stream ONCE, when the
+    autograd engine finishes this backward pass (gradients are only consumed after it), so weight-gradient kernels of
+    one layer overlap the input-gradient chain of the next layers too."""
+    global _JOIN_QUEUED
+    if _SIDE_PENDING and not _JOIN_QUEUED:
+        _JOIN_QUEUED = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_all_side_streams)
+
+
+_WGRAD_QUEUE: List[tuple] = []
+_WGRAD_BATCHING = True
+
+
+def set_wgrad_batching(enabled: bool) -> None:
+    """A/B switch: queue a layer's weight gradients and launch them as one batched kernel (default on)."""
+    global _WGRAD_BATCHING
+    _WGRAD_BATCHING = bool(enabled)
+
+
+def queue_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale: Optional[torch.Tensor] = None,
+                dbias: Optional[torch.Tensor] = None) -> None:
+    """Like gemm_wgrad, but deferred until flush_wgrads() so that independent weight gradients share one launch."""
+    if dC.size(0) == 0:
+        return
+    if not _WGRAD_BATCHING:
+        gemm_wgrad(dC, A, dW, rowscale=rowscale, dbias=dbias)
+        return
+    _WGRAD_QUEUE.append((dC, A, dW, rowscale, dbias))
+
+
+def flush_wgrads() -> None:
+    """Launch every queued weight gradient: up to 8 problems per kernel (gnx_gemm_wgrad_batched), on the side stream
+    when enabled.  Problems that do not meet the batched kernel's alignment rules go through gemm_wgrad."""
+    global _WGRAD_QUEUE
+    jobs, _WGRAD_QUEUE = _WGRAD_QUEUE, []
+    if not jobs:
+        return
+    batchable, rest = [], []
+    for j in jobs:
+        dC, A, dW, rs, db = j
+        ok = all(t is None or t.data_ptr() % 16 == 0 for t in (dC, A)) and dC.stride(0) % 4 == 0 and \
+            A.stride(0) % 4 == 0 and dC.size(1) % 4 == 0 and A.size(1) % 4 == 0 and dC.size(0) > 1 and \
+            (dC.size(1) == 1 or dC.stride(1) == 1) and (A.size(1) == 1 or A.stride(1) == 1)
+        (batchable if ok else rest).append(j)
+    for dC, A, dW, rs, db in rest:
+        gemm_wgrad(dC, A, dW, rowscale=rs, dbias=db)
+    # largest row counts first so that problems of similar size share a launch
+    batchable.sort(key=lambda j: -j[0].size(0))
+    for i in range(0, len(batchable), 8):
+        chunk = batchable[i:i + 8]
+        arr = (_lib.WgradProb * len(chunk))()
+        keep = []
+        for k, (dC, A, dW, rs, db) in enumerate(chunk):
+            xp, ldx = _mat(dC, "dC")
+            ap, lda = _mat(A, "A")
+            wp, ldw = _mat(dW, "dW")
+            M, N = dC.shape
+            K = A.size(1)
+            if A.size(0) != M or dW.size(0) != N or dW.size(1) != K:
+                raise _lib.GnxError(_lib.GNX_E_INVALID, f"wgrad shapes dC {tuple(dC.shape)} A {tuple(A.shape)} "
+                                                        f"dW {tuple(dW.shape)}")
+            arr[k].dC, arr[k].lddc, arr[k].A, arr[k].lda = xp, ldx, ap, lda
+            arr[k].rowscale, arr[k].dW, arr[k].lddw, arr[k].dbias = _ptr(rs), wp, ldw, _ptr(db)
+            arr[k].M, arr[k].N, arr[k].K = M, N, K
+            keep += [dC, A, rs]
+        ref = chunk[0][0]
+        n = len(chunk)
+        _run_on_side(ref, keep, lambda arr=arr, n=n, ref=ref: check(
+            _lib.load().gnx_gemm_wgrad_batched(handle(ref.device), n, arr)))
+
+
 def join_side_stream(device: torch.device) -> None:
     """Make the current stream wait for all weight-gradient kernels issued on the side stream."""
     idx = device.index if device.index is not None else torch.cuda.current_device()

@@ -141,6 +141,23 @@ int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t 
 int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
                        const float* rowscale, int64_t M, int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias);
 
+/* several independent weight gradients in ONE launch (a layer's same-shaped dW += dC^T (rs*A) products share the grid:
+ * every workgroup gets an nprob x longer row range, so the atomic flush per problem shrinks nprob x).  nprob <= 8;
+ * every operand 16-byte aligned with leading dimensions, N and K multiples of 4. */
+typedef struct {
+  const float* dC;       /* [M, N], ld lddc */
+  int64_t lddc;
+  const float* A;        /* [M, K], ld lda */
+  int64_t lda;
+  const float* rowscale; /* [M] or NULL */
+  float* dW;             /* [N, K], ld lddw (accumulated) */
+  int64_t lddw;
+  float* dbias;          /* [N] or NULL (accumulated) */
+  int64_t M;
+  int32_t N, K;
+} gnx_wgrad_prob;
+int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gnx_wgrad_prob* probs);
+
 /* ---- in-degree classes: PNA post-layer 0 with one effective weight per degree ------------------------------- */
 /* amp/att of [3P] DegreeScalerAggregation depend on the in-degree d only, so
  *     [x | A | amp*A | att*A] W^T  =  x W0^T + A (W1 + amp(d) W2 + att(d) W3)^T  =  x W0^T + A Weff(d)^T
