@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-side-stream", action="store_true", help="keep weight-gradient kernels on the main stream")
     ap.add_argument("--no-degree-classes", action="store_true", help="PNA post-layer 0 as the 13F-wide 4-segment product")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into a HIP graph and replay it (measured: no gain over eager launches here — "
+                         "dependent-kernel boundaries cost the same either way and the CPU already runs ahead)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,6 +75,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback for the product path)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # everything (warm-up, capture, replay) runs on ONE non-default stream: autograd's AccumulateGrad nodes remember the
+    # stream they were created on, and a node bound to the legacy default stream cannot take part in a graph capture
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
 
     from gnnepcsaft_amd import _lib, dp, functional as Fn, ops
     from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
@@ -98,21 +105,52 @@ def main():
     N_nodes, E_edges = b.x.size(0), b.edge_index.size(1)
     H, T = cfg["hidden_dim"], cfg["towers"]
 
-    def step():
+    # sync-free packing: PNA's own in-degree histogram bounds the degree (a batch above it trips the range flag)
+    model.model.max_degree_hint = len(deg) - 1
+
+    def step_body():
         flat.zero_grad()
         b._gnx_pack = None  # a new batch arrives every step in training: the packer is part of the step
         loss = model.training_step(b, 0)
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = step_body()
         flat.all_reduce()
         return loss
 
     for _ in range(args.warmup):
-        loss = step()
+        loss = eager_step()
     ops.check_range(dev)  # validates the integer inputs of the warm-up steps (sync)
     torch.cuda.synchronize()
+
+    # Optional: the whole step (pack + forward + loss + backward, both streams) captured once into a HIP graph and
+    # replayed; the batch lives in static device buffers.  The gradient all-reduce stays outside the graph.
+    step = eager_step
+    graphed = False
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=main_stream):
+                static_loss = step_body()
+
+            def graph_step():
+                graph.replay()
+                flat.all_reduce()
+                return static_loss
+
+            for _ in range(2):
+                graph_step()
+            torch.cuda.synchronize()
+            step, graphed = graph_step, True
+        except Exception as e:  # pylint: disable=broad-except
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            step = eager_step
+
     agg_k = _lib.K_PNA_AGG_FWD if cfg["conv"] == "PNA" else _lib.K_GINE_AGG_FWD
     agg_bk = _lib.K_PNA_AGG_BWD if cfg["conv"] == "PNA" else _lib.K_GINE_AGG_BWD
-    ops.prof_begin(dev, [agg_k, agg_bk, _lib.K_GEMM, _lib.K_GEMM_WGRAD])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -125,6 +163,12 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     ops.check_range(dev)
+    # per-kernel durations: HIP events around every launch of the named kernels on their launch stream, over `steps`
+    # eager steps of the same workload (event records cannot live inside the replayed graph)
+    ops.prof_begin(dev, [agg_k, agg_bk, _lib.K_GEMM, _lib.K_GEMM_WGRAD])
+    for _ in range(args.steps):
+        eager_step()
+    torch.cuda.synchronize()
     n_f, ms_f = ops.prof_read(dev, agg_k)
     n_b, ms_b = ops.prof_read(dev, agg_bk)
     n_g, ms_g = ops.prof_read(dev, _lib.K_GEMM)
@@ -166,7 +210,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {cfg['conv']} hidden={H} L={cfg['propagation_depth']} "
                                    f"towers={T} pre={cfg['pre_layers']} post={cfg['post_layers']}, {per_gpu} graphs/GPU "
                                    f"({N_nodes} atoms, {E_edges} directed bonds), fwd+loss+bwd incl. CSR packing",
-                       "graphs_per_gpu": per_gpu, "parallelism": f"dp{world}",
+                       "graphs_per_gpu": per_gpu, "parallelism": f"dp{world}", "hip_graph": graphed,
                        "grad_allreduce_bytes": flat.nbytes if world > 1 else 0},
             "loss": loss_val,
             "roofline": {"bound": "hbm", "kernel": "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd",

@@ -69,6 +69,8 @@ SIGNATURES = {
                                       _i64]),
     "gnx_pna_weff": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "gnx_pna_weff_bwd": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _i64]),
+    "gnx_group_by_small_key": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz]),
+    "gnx_key_segment_sum": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "gnx_edge_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz]),
     "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

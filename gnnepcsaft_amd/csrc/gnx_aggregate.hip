@@ -326,6 +326,82 @@ extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int
   return GNX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// dTable[r,:] += sum over the items of key r of g[item,:]  through the inverted index (pos grouped by key, ptr).
+// One workgroup = SEG_CHUNK consecutive entries of pos; a thread owns 4 channels and sums rows in registers, flushing
+// with one atomic per (key run inside the chunk): ~ (#chunks + #keys) x H atomics in total instead of items x H.
+// ---------------------------------------------------------------------------------------------------------------
+#define SEG_CHUNK 128
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_key_segment_sum(const float* __restrict__ g, const int* __restrict__ pos,
+                                                         const int* __restrict__ key, int64_t E, int H,
+                                                         float* __restrict__ dtable) {
+  const int G = H / VEC;                 // threads per row
+  const int lanes = 256 / G > 0 ? 256 / G : 1;  // row lanes per block
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  if (rl >= lanes) return;
+  const int c = cg * VEC;
+  const int64_t i0 = (int64_t)blockIdx.x * SEG_CHUNK;
+  int64_t i1 = i0 + SEG_CHUNK;
+  if (i1 > E) i1 = E;
+  // each row lane walks a contiguous sub-run so that key changes are rare inside it
+  const int64_t per = (i1 - i0 + lanes - 1) / lanes;
+  int64_t a = i0 + (int64_t)rl * per, b = a + per;
+  if (b > i1) b = i1;
+  if (a >= b) return;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  int cur = key[pos[a]];
+  constexpr int UN = 4;  // items in flight: index loads batched, then the row gathers batched (2 round trips per 4)
+  for (int64_t i = a; i < b; i += UN) {
+    int p[UN], k[UN];
+    float r[UN][VEC];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) p[j] = pos[(i + j < b) ? i + j : b - 1];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) k[j] = key[p[j]];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) vload<VEC>(r[j], g + (int64_t)p[j] * H + c);
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      if (i + j < b) {
+        if (k[j] != cur) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) atomicAdd(&dtable[(int64_t)cur * H + c + v], acc[v]);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+          cur = k[j];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += r[j][v];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) atomicAdd(&dtable[(int64_t)cur * H + c + v], acc[v]);
+}
+
+extern "C" int32_t gnx_key_segment_sum(gnx_handle* h, const float* g, const int32_t* pos, const int32_t* key, int64_t E,
+                                       int32_t H, float* dtable) {
+  GNX_CHECK_ARG(h && H > 0 && E >= 0, "gnx_key_segment_sum: bad argument");
+  if (E == 0) return GNX_OK;
+  GNX_CHECK_ARG(g && pos && key && dtable, "gnx_key_segment_sum: NULL argument");
+  const unsigned blocks = (unsigned)gnx_cdiv(E, SEG_CHUNK);
+  if (H % 4 == 0 && H / 4 <= 256)
+    hipLaunchKernelGGL(k_key_segment_sum<4>, dim3(blocks), dim3(256), 0, h->stream, g, pos, key, E, (int)H, dtable);
+  else if (H <= 256)
+    hipLaunchKernelGGL(k_key_segment_sum<1>, dim3(blocks), dim3(256), 0, h->stream, g, pos, key, E, (int)H, dtable);
+  else {
+    gnx_set_error("gnx_key_segment_sum: H=%d not supported (H %% 4 == 0 and H <= 1024, or H <= 256)", H);
+    return GNX_E_INVALID;
+  }
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // GINE: out[i] = (1+eps) x[i] + sum_{p in row i} relu(x[src[p]] + Le[code[p]])
 // ---------------------------------------------------------------------------------------------------------------

@@ -69,7 +69,8 @@ extern "C" int32_t gnx_check_range(gnx_handle* h) {
   int32_t st = gnx_read_flag(h, &v);
   if (st != GNX_OK) return st;
   if (v != 0) {
-    gnx_set_error("integer input out of range:%s%s%s%s%s", (v & 1) ? " edge_index holds a node id outside [0,N);" : "",
+    gnx_set_error("integer input out of range:%s%s%s%s%s%s", (v & 32) ? " an in-degree (or bond code) exceeds the caller's hint;" : "",
+                  (v & 1) ? " edge_index holds a node id outside [0,N);" : "",
                   (v & 2) ? " edge/node feature outside its vocabulary;" : "",
                   (v & 4) ? " batch holds a graph id outside [0,B);" : "", (v & 8) ? " batch is not sorted;" : "",
                   (v & 16) ? " embedding index outside its table;" : "");

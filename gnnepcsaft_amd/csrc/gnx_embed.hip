@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_table_scatter_add(const IdxT* __restric
   if (col < H && r0 < r1) {
     // four rows in flight per thread; every load is unconditional (clamped row) and issued before any use, so one
     // round trip serves 4 rows x (1 gradient quad + 1 index) instead of a dependent chain per row
-    constexpr int UN = 4;
+    constexpr int UN = (VEC == 1) ? 8 : 4;
     for (int64_t n = r0 + rl; n < r1; n += UN * RL) {
       int64_t nn[UN];
       bool ok[UN];
@@ -200,7 +200,10 @@ static int32_t launch_table_scatter_add(gnx_handle* h, const IdxT* idx, int64_t 
     }
     part = reinterpret_cast<float*>(ws);
   }
-  if (H % 4 == 0)
+  // One column per lane: a wave's ds_add_f32 then touches 64 consecutive floats (2 lanes per bank, the minimum).  The
+  // float4-per-thread layout put every lane of an instruction on 8 banks (8-way conflict on the LDS atomic unit:
+  // 106 us for a 163840 x 128 gradient instead of ~25 us), so it is not used even when H % 4 == 0.
+  if (false)
     hipLaunchKernelGGL((k_table_scatter_add<IdxT, 4>), dim3((unsigned)chunks, (unsigned)slabs), dim3(256),
                        (size_t)R * CW * sizeof(float), h->stream, idx, N, K, o, R, dout, H, CW, rows_per_block, dtable,
                        part);

@@ -328,15 +328,21 @@ extern "C" int32_t gnx_degree_max(gnx_handle* h, const int32_t* rowptr, int64_t 
 #define DC_MAX_CLASSES 64
 
 // blockhist[d * nblocks + b] = #nodes of block b with in-degree d
-__global__ void __launch_bounds__(DC_BLOCK) k_dc_hist(const int* __restrict__ rowptr, int64_t N, int D, int nblocks,
-                                                       int* __restrict__ blockhist) {
+// keys != NULL: key of item n = keys[n]; else key = in-degree rowptr[n+1]-rowptr[n]
+__global__ void __launch_bounds__(DC_BLOCK) k_dc_hist(const int* __restrict__ rowptr, const int* __restrict__ keys,
+                                                       int64_t N, int D, int nblocks, int* __restrict__ blockhist,
+                                                       int* __restrict__ flag) {
   __shared__ int hist[DC_MAX_CLASSES];
   if (threadIdx.x < DC_MAX_CLASSES) hist[threadIdx.x] = 0;
   __syncthreads();
   int64_t n = (int64_t)blockIdx.x * DC_BLOCK + threadIdx.x;
   if (n < N) {
-    int d = rowptr[n + 1] - rowptr[n];
-    if (d >= D) d = D - 1;  // cannot happen when D = max degree + 1
+    int d = keys ? keys[n] : rowptr[n + 1] - rowptr[n];
+    if (d < 0) d = 0;
+    if (d >= D) {  // only possible when D came from a caller's hint: reported through the sticky flag (bit 5)
+      atomicOr(flag, 32);
+      d = D - 1;
+    }
     atomicAdd(&hist[d], 1);
   }
   __syncthreads();
@@ -344,14 +350,16 @@ __global__ void __launch_bounds__(DC_BLOCK) k_dc_hist(const int* __restrict__ ro
 }
 
 // stable position of every node: scanned block offset of its (class, block) + rank among earlier same-class threads
-__global__ void __launch_bounds__(DC_BLOCK) k_dc_fill(const int* __restrict__ rowptr, int64_t N, int D, int nblocks,
+__global__ void __launch_bounds__(DC_BLOCK) k_dc_fill(const int* __restrict__ rowptr, const int* __restrict__ keys,
+                                                       int64_t N, int D, int nblocks,
                                                        const int* __restrict__ blockoff, int* __restrict__ dperm,
                                                        int* __restrict__ cls_ptr) {
   __shared__ int degs[DC_BLOCK];
   int64_t n = (int64_t)blockIdx.x * DC_BLOCK + threadIdx.x;
   int d = -1;
   if (n < N) {
-    d = rowptr[n + 1] - rowptr[n];
+    d = keys ? keys[n] : rowptr[n + 1] - rowptr[n];
+    if (d < 0) d = 0;
     if (d >= D) d = D - 1;
   }
   degs[threadIdx.x] = d;
@@ -384,12 +392,39 @@ extern "C" int32_t gnx_degree_classes(gnx_handle* h, const int32_t* rowptr, int6
   int* blockhist = reinterpret_cast<int*>(ws);
   int* blockoff = blockhist + (size_t)D * nblocks + 1;
   int* scan_ws = blockoff + (size_t)D * nblocks + 1;
-  hipLaunchKernelGGL(k_dc_hist, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, N, (int)D, nblocks, blockhist);
+  hipLaunchKernelGGL(k_dc_hist, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, (const int*)nullptr, N, (int)D,
+                     nblocks, blockhist, h->d_flag);
   GNX_LAUNCH_CHECK();
   int32_t st = exclusive_scan(h, blockhist, blockoff, (int64_t)D * nblocks, scan_ws, false);
   if (st != GNX_OK) return st;
-  hipLaunchKernelGGL(k_dc_fill, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, N, (int)D, nblocks, blockoff, dperm,
-                     cls_ptr);
+  hipLaunchKernelGGL(k_dc_fill, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, rowptr, (const int*)nullptr, N, (int)D,
+                     nblocks, blockoff, dperm, cls_ptr);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+// Stable grouping of E items by a small integer key (0 <= key < R <= 64): pos int32[E] = item ids sorted by key
+// (ascending id inside a key), ptr int32[R+1].  Used for the per-edge bond code: the inverted index lets the bond-table
+// gradient be a gather-sum over contiguous index runs instead of 10^7 atomics.  ws: gnx_degree_classes_workspace_bytes(E, R).
+extern "C" int32_t gnx_group_by_small_key(gnx_handle* h, const int32_t* keys, int64_t E, int32_t R, int32_t* pos,
+                                          int32_t* ptr, void* ws, size_t ws_bytes) {
+  GNX_CHECK_ARG(h && ptr && E >= 0 && R >= 1 && R <= DC_MAX_CLASSES && (E == 0 || (keys && pos)),
+                "gnx_group_by_small_key: bad argument (R must be in [1,%d])", DC_MAX_CLASSES);
+  if (ws_bytes < gnx_degree_classes_workspace_bytes(E, R) || !ws) {
+    gnx_set_error("gnx_group_by_small_key: workspace %zu < %zu", ws_bytes, gnx_degree_classes_workspace_bytes(E, R));
+    return GNX_E_WORKSPACE;
+  }
+  int nblocks = (int)gnx_cdiv(E > 0 ? E : 1, DC_BLOCK);
+  int* blockhist = reinterpret_cast<int*>(ws);
+  int* blockoff = blockhist + (size_t)R * nblocks + 1;
+  int* scan_ws = blockoff + (size_t)R * nblocks + 1;
+  hipLaunchKernelGGL(k_dc_hist, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, (const int*)nullptr, keys, E, (int)R,
+                     nblocks, blockhist, h->d_flag);
+  GNX_LAUNCH_CHECK();
+  int32_t st = exclusive_scan(h, blockhist, blockoff, (int64_t)R * nblocks, scan_ws, false);
+  if (st != GNX_OK) return st;
+  hipLaunchKernelGGL(k_dc_fill, dim3(nblocks), dim3(DC_BLOCK), 0, h->stream, (const int*)nullptr, keys, E, (int)R,
+                     nblocks, blockoff, pos, ptr);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

@@ -202,7 +202,7 @@ class PNAConvFn(torch.autograd.Function):
         z = _empty(N, H, x)
         # post-layer 0: amp/att depend on the in-degree only, so with rows grouped by degree class the 12F-wide scaled
         # operand collapses to A @ Weff(d)^T (26NF^2 -> 10NF^2 FLOPs); hub-heavy batches (>64 classes) keep 4 segments
-        dc = pack.degree_classes() if _USE_DEGREE_CLASSES else None
+        dc = pack.degree_classes(pack.max_degree_hint) if _USE_DEGREE_CLASSES else None
         weffs = []
         for t in range(T):
             Wp, bp = post[t][0]

@@ -50,15 +50,31 @@ class GraphPack:
     """
 
     __slots__ = ("N", "E", "B", "rowptr", "perm", "src", "dst", "colptr", "cpos", "code", "graph_ptr", "device",
-                 "_scalers", "has_batch", "_classes")
+                 "_scalers", "has_batch", "_classes", "_code_index", "max_degree_hint")
 
-    def degree_classes(self) -> Optional["DegreeClasses"]:
+    def code_index(self, R: int) -> Optional[torch.Tensor]:
+        """CSR positions stably grouped by bond code (inverted index for the bond-table gradient); None if R > 64."""
+        if R > 64:
+            return None
+        if self._code_index is None or self._code_index[0] != R:
+            lib, h = _lib.load(), handle(self.device)
+            pos = torch.empty(max(self.E, 1), dtype=torch.int32, device=self.device)
+            ptr = torch.empty(R + 1, dtype=torch.int32, device=self.device)
+            nbytes = lib.gnx_degree_classes_workspace_bytes(self.E, R)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(lib.gnx_group_by_small_key(h, self.code.data_ptr(), self.E, R, pos.data_ptr(), ptr.data_ptr(),
+                                             ws.data_ptr(), nbytes))
+            self._code_index = (R, pos, ptr)
+        return self._code_index[1]
+
+    def degree_classes(self, max_degree_hint: Optional[int] = None) -> Optional["DegreeClasses"]:
         """Nodes grouped by in-degree (for PNA's per-degree effective post-layer-0 weight); ``None`` when the batch
         has more than 64 distinct degrees up to its maximum (hub-heavy graphs use the ungrouped 4-segment product).
-        Built once per batch; reads the maximum in-degree back from the device (one sync, like PyG's
-        ``batch.max()``)."""
+        Built once per batch.  Without a hint the maximum in-degree is read back from the device (one sync, like
+        PyG's ``batch.max()``); with ``max_degree_hint`` (e.g. ``len(config["deg"]) - 1``) nothing synchronises and a
+        node above the hint sets the sticky range flag reported by ``check_range`` (needed under HIP-graph capture)."""
         if self._classes is None:
-            self._classes = DegreeClasses.build(self)
+            self._classes = DegreeClasses.build(self, max_degree_hint)
         return self._classes if self._classes.D <= DegreeClasses.MAX_D else None
 
     def degree_scalers(self, avg_deg_log: float) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -83,12 +99,15 @@ class DegreeClasses:
     __slots__ = ("D", "dperm", "cls_ptr", "tiles", "ntiles", "max_tiles", "chunks", "nchunks", "max_chunks")
 
     @staticmethod
-    def build(g: "GraphPack") -> "DegreeClasses":
+    def build(g: "GraphPack", max_degree_hint: Optional[int] = None) -> "DegreeClasses":
         lib, h = _lib.load(), handle(g.device)
         dc = DegreeClasses()
-        mx = _I32(0)
-        check(lib.gnx_degree_max(h, g.rowptr.data_ptr(), g.N, C.byref(mx)))
-        dc.D = int(mx.value) + 1
+        if max_degree_hint is None:
+            mx = _I32(0)
+            check(lib.gnx_degree_max(h, g.rowptr.data_ptr(), g.N, C.byref(mx)))
+            dc.D = int(mx.value) + 1
+        else:
+            dc.D = int(max_degree_hint) + 1
         if dc.D > DegreeClasses.MAX_D:
             return dc
         i32 = dict(dtype=torch.int32, device=g.device)
@@ -129,7 +148,8 @@ def pack_graph(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], batc
     N, E = int(num_nodes), int(edge_index.size(1))
     i32 = dict(dtype=torch.int32, device=dev)
     g = GraphPack()
-    g.N, g.E, g.device, g._scalers, g._classes = N, E, dev, {}, None
+    g.N, g.E, g.device, g._scalers, g._classes, g._code_index = N, E, dev, {}, None, None
+    g.max_degree_hint = None
     g.rowptr = torch.empty(N + 1, **i32)
     g.colptr = torch.empty(N + 1, **i32)
     g.perm = torch.empty(E, **i32)
@@ -468,6 +488,15 @@ def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tens
     dQ = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
     dTe = torch.zeros(R, H, dtype=torch.float32, device=gr.device)
     lib = _lib.load()
+    pos = g.code_index(R) if (H % 4 == 0 and H <= 1024) or H <= 256 else None
+    if pos is not None:
+        # bond-table gradient through the inverted index (gather-sum, no LDS atomics); dP/dQ from the same call
+        check(lib.gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
+                                       g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(),
+                                       dQ.data_ptr(), None, None, 0))
+        check(lib.gnx_key_segment_sum(handle(gr.device), gr.data_ptr(), pos.data_ptr(), g.code.data_ptr(), g.E, H,
+                                      dTe.data_ptr()))
+        return dP, dQ, dTe
     nbytes = lib.gnx_table_scatter_workspace_bytes(g.E, R, H)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=gr.device)
     check(lib.gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),

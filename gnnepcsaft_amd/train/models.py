@@ -24,7 +24,7 @@ from .lightning_lite import LightningModuleLite
 _OUT_OF_SCOPE_CONVS = ("GCN", "GAT", "GATv2", "Transformer", "SAGE", "GIN", "Edge", "GatedGraph", "Graph", "ARMA", "SG")
 
 
-def _pack_of(graphs, validate: bool) -> GraphPack:
+def _pack_of(graphs, validate: bool, max_degree_hint: Optional[int] = None) -> GraphPack:
     """GraphPack of a Batch-like object, cached on it (the packer runs once per batch, like PyG's collate)."""
     pack = getattr(graphs, "_gnx_pack", None)
     if pack is None or pack.device != graphs.x.device:
@@ -32,6 +32,7 @@ def _pack_of(graphs, validate: bool) -> GraphPack:
         num_graphs = getattr(graphs, "num_graphs", None) if batch is not None else None
         pack = ops.pack_graph(graphs.edge_index, graphs.edge_attr, batch, graphs.x.size(0), num_graphs,
                               validate=validate)
+        pack.max_degree_hint = max_degree_hint
         try:
             graphs._gnx_pack = pack
         except AttributeError:
@@ -80,7 +81,8 @@ class GNNePCSAFTL(LightningModuleLite):
         else:
             target: torch.Tensor = graphs.para
         x, edge_index, edge_attr, batch = graphs.x, graphs.edge_index, graphs.edge_attr, graphs.batch
-        pred: torch.Tensor = self(x, edge_index, edge_attr, batch, pack=_pack_of(graphs, self.model.validate_inputs))
+        pred: torch.Tensor = self(x, edge_index, edge_attr, batch,
+                                  pack=_pack_of(graphs, self.model.validate_inputs, self.model.max_degree_hint))
         # ape = (pred - target) / target ; huber(ape, 0, delta=0.01) ; mape(pred, target) -- one kernel
         loss, both = Fn.HuberAPEFn.apply(pred, target, 0.01)
         self.log("train_huber", loss, on_step=True, batch_size=target.shape[0], sync_dist=True)
@@ -152,6 +154,9 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
         )
         # integer inputs are range-checked on device; True = read the flag back (one sync) when a batch is packed
         self.validate_inputs = True
+        # sync-free packing (HIP-graph capture): upper bound of the in-degree, e.g. len(config["deg"]) - 1; a batch that
+        # exceeds it trips the range flag (ops.check_range).  None = read the batch's maximum back (one sync).
+        self.max_degree_hint = None
         self._bounds_cache = {}
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,

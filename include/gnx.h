@@ -202,6 +202,14 @@ int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int32_t* rowpt
                              const int32_t* cpos, const int32_t* code, int64_t N, int64_t E, int32_t H, int32_t R,
                              float* dP, float* dQ, float* dTe, void* ws, size_t ws_bytes);
 
+/* inverted index by a small integer key (bond code): pos int32[E] = item ids stably grouped by key, ptr int32[R+1];
+ * ws: gnx_degree_classes_workspace_bytes(E, R); R <= 64.  gnx_key_segment_sum: dtable[r,:] += sum_{items of key r} g[item,:]
+ * as a gather-sum over contiguous index runs (no LDS atomics; (#chunks + R) x H global atomics). */
+int32_t gnx_group_by_small_key(gnx_handle* h, const int32_t* keys, int64_t E, int32_t R, int32_t* pos, int32_t* ptr,
+                               void* ws, size_t ws_bytes);
+int32_t gnx_key_segment_sum(gnx_handle* h, const float* g, const int32_t* pos, const int32_t* key, int64_t E, int32_t H,
+                            float* dtable);
+
 /* ---- the scatter-aggregate: PNA mean|min|max|std over target nodes  (HBM-bound; the roofline kernel) ------- */
 /* [3P] MultiAggregation([Mean,Min,Max,Std], mode='cat') as used by DegreeScalerAggregation
  * (aggregator list ref: train/models.py:443).  m fp32[E, T*F] in CSR order, rowptr int32[N+1].
