@@ -85,6 +85,8 @@ SIGNATURES = {
                                  _sz]),
     "gnx_batchnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz]),
     "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "gnx_adamw_amsgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
+    "gnx_sgd": (_i32, [_vp, _vp, _vp, _i64, _f32]),
     "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),
     "gnx_clip_rows": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 }

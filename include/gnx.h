@@ -257,6 +257,13 @@ int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float* x, const 
 int32_t gnx_huber_ape(gnx_handle* h, const float* pred, const float* target, int64_t count, float delta, float* out2,
                       float* dpred);
 
+/* ---- optimizer step on device (ref: train/models.py:47-63) ----------------------------------- */
+/* torch.optim.AdamW(amsgrad=True) single-tensor arithmetic over flat fp32 buffers of n elements; step counts from 1. */
+int32_t gnx_adamw_amsgrad(gnx_handle* h, float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step);
+/* torch.optim.SGD(momentum=0, weight_decay=0, nesterov=False): p -= lr * g */
+int32_t gnx_sgd(gnx_handle* h, float* p, const float* g, int64_t n, float lr);
+
 /* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
 int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
 /* y[m,:] = clip(x[m,:], lo[:], hi[:])   (pred_with_bounds, ref: train/models.py:246-253) */
