@@ -1,0 +1,132 @@
+"""Minimal trainer with ``lightning.Trainer.fit``'s call shape for the GNN path — what
+``ltrain_and_evaluate`` needs from Lightning at /root/reference/gnnepcsaft/train/train.py:85-115 (``max_steps``,
+``log_every_n_steps``, ``val_check_interval``, several validation loaders, ``ckpt_path``) — plus a ``DataLoader`` that
+collates like PyG's.  Orchestration only (Ray / wandb / absl stay out of scope); every step runs the HIP path.
+
+One process per GPU: if ``torch.distributed`` is initialised, gradients are averaged with one flat all-reduce per step
+(``dp.FlatGradAllReduce``) and logged scalars are averaged for ``sync_dist``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import dp, functional as Fn, ops
+from ..data.batching import Batch, Data
+from ..optim import configure_fused_optimizers
+
+
+class DataLoader:
+    """Batches a list of ``Data`` with ``Batch.from_data_list`` (PyG DataLoader semantics: optional shuffle per epoch,
+    last batch kept)."""
+
+    def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False, seed: int = 0, **_ignored):
+        self.dataset, self.batch_size, self.shuffle = list(dataset), int(batch_size), bool(shuffle)
+        self._rng = np.random.Generator(np.random.PCG64(seed))
+
+    def __len__(self) -> int:
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = np.arange(len(self.dataset))
+        if self.shuffle:
+            self._rng.shuffle(order)
+        for i in range(0, len(order), self.batch_size):
+            yield Batch.from_data_list([self.dataset[j] for j in order[i:i + self.batch_size]])
+
+
+class Trainer:
+    def __init__(self, max_steps: int = -1, log_every_n_steps: int = 50, val_check_interval: Optional[int] = None,
+                 default_root_dir: Optional[str] = None, enable_checkpointing: bool = True, fused_optimizer: bool = True,
+                 device: Optional[str] = None, **_ignored):
+        self.max_steps, self.log_every_n_steps = int(max_steps), int(log_every_n_steps)
+        self.val_check_interval = val_check_interval
+        self.default_root_dir = default_root_dir
+        self.enable_checkpointing = enable_checkpointing
+        self.fused_optimizer = fused_optimizer
+        self.device = torch.device(device) if device else torch.device("cuda", torch.cuda.current_device())
+        self.global_step = 0
+        self.current_epoch = 0
+        self.logged: List[dict] = []
+        self.validation_results: List[dict] = []
+
+    # ------------------------------------------------------------------------------------------------------------
+    def save_checkpoint(self, model, path: str) -> None:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": self.current_epoch,
+                    "hyper_parameters": {"config": dict(model.config)}}, path)
+
+    @staticmethod
+    def load_state_dict(model, path: str) -> dict:
+        """Reads a checkpoint's ``state_dict`` (this trainer's, or a Lightning ``.ckpt`` whose payload the safe loader
+        accepts) with ``weights_only=True`` — nothing from the file is executed."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        model.load_state_dict(ckpt["state_dict"])
+        return ckpt
+
+    # ------------------------------------------------------------------------------------------------------------
+    def fit(self, model, train_dataloaders: Iterable, val_dataloaders: Optional[Sequence[Iterable]] = None,
+            ckpt_path: Optional[str] = None) -> None:
+        model.to(self.device)
+        model.train()
+        model.trainer = self
+        if ckpt_path:
+            ckpt = self.load_state_dict(model, ckpt_path)
+            self.global_step = int(ckpt.get("global_step", 0))
+        dp.broadcast_parameters(model)
+        grads = dp.FlatGradAllReduce(model)
+        oc = configure_fused_optimizers(model, grads) if self.fused_optimizer else model.configure_optimizers()
+        opt = oc["optimizer"]
+        sched, freq = oc["lr_scheduler"]["scheduler"], int(oc["lr_scheduler"].get("frequency", 1))
+        prev_in_place = Fn._GRAD_IN_PLACE  # pylint: disable=protected-access
+        Fn.set_grad_in_place(self.fused_optimizer)
+        model.model.validate_inputs = False  # one range check per logging interval instead of one sync per batch
+        try:
+            while self.max_steps < 0 or self.global_step < self.max_steps:
+                for batch in train_dataloaders:
+                    b = batch.to(self.device, non_blocking=True)
+                    if self.fused_optimizer:
+                        opt.zero_grad()
+                    else:
+                        grads.zero_grad()
+                    loss = model.training_step(b, self.global_step)
+                    loss.backward()
+                    grads.all_reduce()
+                    opt.step()
+                    self.global_step += 1
+                    model.global_step = self.global_step
+                    if self.global_step % self.log_every_n_steps == 0:
+                        ops.check_range(self.device)
+                        rec = dp.reduce_logged(model.logged_metrics)
+                        rec.update(step=self.global_step, epoch=self.current_epoch, lr=opt.param_groups[0]["lr"])
+                        self.logged.append(rec)
+                    if self.val_check_interval and val_dataloaders and \
+                            self.global_step % int(self.val_check_interval) == 0:
+                        self._validate(model, val_dataloaders)
+                    if 0 <= self.max_steps <= self.global_step:
+                        break
+                self.current_epoch += 1
+                if self.current_epoch % freq == 0:  # "interval": "epoch", "frequency": 10 (models.py:72-73)
+                    sched.step()
+                if self.max_steps < 0:
+                    break  # one epoch when no step budget is given
+        finally:
+            Fn.set_grad_in_place(prev_in_place)
+        ops.check_range(self.device)
+        if self.enable_checkpointing and self.default_root_dir:
+            self.save_checkpoint(model, os.path.join(self.default_root_dir, "last.ckpt"))
+
+    def _validate(self, model, val_dataloaders) -> None:
+        if model.rho_batch is None or model.vp_batch is None:
+            return  # the CPU PC-SAFT oracle is not wired in: nothing to evaluate (see GNNePCSAFTL.validation_step)
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            for idx, loader in enumerate(val_dataloaders):
+                for i, batch in enumerate(loader):
+                    out = model.validation_step(batch.to(self.device), i, idx)
+                    self.validation_results.append({"step": self.global_step, "dataloader_idx": idx, **out})
+        model.train(was_training)
