@@ -9,6 +9,7 @@
 #include "gnx_common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 int32_t gnx_code_scatter_add(gnx_handle* h, const int32_t* code, int64_t E, int R, const float* g, int H,
                              float* dtable, void* ws, size_t ws_bytes);
@@ -209,12 +210,114 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
   }
 }
 
+
+// Variant that does not read the saved aggregate A: mean / min / max / std are recomputed from the message rows with the
+// forward's exact arithmetic (same bits, so the std mask decision is identical), which drops 16NH bytes of reads — the
+// rows of one destination (<= a few KB) are re-read from L1/L2 by the tie-count and write passes.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict__ dA, const float* __restrict__ m,
+                                                        const int* __restrict__ rowptr, int64_t N, int T, int F,
+                                                        float* __restrict__ dm) {
+  const int H = T * F;
+  const int G = H / VEC;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * G) return;
+  int64_t n = t / G;
+  int c = (int)(t % G) * VEC;
+  int p0 = rowptr[n], p1 = rowptr[n + 1];
+  if (p1 <= p0) return;
+  int tw = c / F, f = c % F;
+  int64_t ao = (n * T + tw) * (int64_t)(4 * F) + f;
+  float gmean[VEC], gmn[VEC], gmx[VEC], gsd[VEC];
+  vload<VEC>(gmean, dA + ao);
+  vload<VEC>(gmn, dA + ao + F);
+  vload<VEC>(gmx, dA + ao + 2 * F);
+  vload<VEC>(gsd, dA + ao + 3 * F);
+  float s[VEC], s2[VEC], mn[VEC], mx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    s[v] = 0.f;
+    s2[v] = 0.f;
+    mn[v] = INFINITY;
+    mx[v] = -INFINITY;
+  }
+  const float* mp = m + (int64_t)p0 * H + c;
+  for (int p = p0; p < p1; ++p, mp += H) {  // same order and roundings as k_pna_agg_fwd
+    float a[VEC];
+    vload<VEC>(a, mp);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      s[v] = __fadd_rn(s[v], a[v]);
+      s2[v] = __fadd_rn(s2[v], __fmul_rn(a[v], a[v]));
+      mn[v] = fminf(mn[v], a[v]);
+      mx[v] = fmaxf(mx[v], a[v]);
+    }
+  }
+  const float cnt = (float)(p1 - p0);
+  float mean[VEC], sd[VEC], nmn[VEC], nmx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    mean[v] = __fdiv_rn(s[v], cnt);
+    float mean2 = __fdiv_rn(s2[v], cnt);
+    float var = __fsub_rn(mean2, __fmul_rn(mean[v], mean[v]));
+    float o = __fsqrt_rn(fmaxf(var, STD_VAR_MIN));
+    sd[v] = (o <= STD_MASK_AT) ? 0.f : o;
+    nmn[v] = (mn[v] == 0.f) ? 1.f : 0.f;  // torch's zero-filled self counts as a tie (see k_pna_agg_bwd)
+    nmx[v] = (mx[v] == 0.f) ? 1.f : 0.f;
+  }
+  mp = m + (int64_t)p0 * H + c;
+  for (int p = p0; p < p1; ++p, mp += H) {
+    float a[VEC];
+    vload<VEC>(a, mp);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      nmn[v] += (a[v] == mn[v]) ? 1.f : 0.f;
+      nmx[v] += (a[v] == mx[v]) ? 1.f : 0.f;
+    }
+  }
+  float k_mean[VEC], k_mn[VEC], k_mx[VEC], k_sd[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    k_mean[v] = gmean[v] / cnt;
+    k_mn[v] = gmn[v] / nmn[v];
+    k_mx[v] = gmx[v] / nmx[v];
+    k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sd[v]) : 0.f;
+  }
+  mp = m + (int64_t)p0 * H + c;
+  float* dp = dm + (int64_t)p0 * H + c;
+  for (int p = p0; p < p1; ++p, mp += H, dp += H) {
+    float a[VEC], o[VEC];
+    vload<VEC>(a, mp);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float r = k_mean[v] + k_sd[v] * (a[v] - mean[v]);
+      r += (a[v] == mn[v]) ? k_mn[v] : 0.f;
+      r += (a[v] == mx[v]) ? k_mx[v] : 0.f;
+      o[v] = r;
+    }
+    vstore<VEC>(dp, o);
+  }
+}
+
 extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A,
                                          const int32_t* rowptr, int64_t N, int32_t T, int32_t F, float* dm) {
   GNX_CHECK_ARG(h && rowptr && T > 0 && F > 0 && N >= 0, "gnx_pna_aggregate_bwd: bad argument");
   GNX_CHECK_ARG(N == 0 || (dA && A), "gnx_pna_aggregate_bwd: NULL argument");
   if (N == 0) return GNX_OK;
   gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD);
+  {
+    const char* e = getenv("GNX_AGG_BWD_RECOMPUTE");
+    if (!(e && atoi(e) == 0)) {
+      if (F % 4 == 0)
+        hipLaunchKernelGGL(k_pna_agg_bwd_rc<4>, dim3((unsigned)gnx_cdiv(N * (T * F / 4), 256)), dim3(256), 0, h->stream,
+                           dA, m, rowptr, N, (int)T, (int)F, dm);
+      else
+        hipLaunchKernelGGL(k_pna_agg_bwd_rc<1>, dim3((unsigned)gnx_cdiv(N * (int64_t)(T * F), 256)), dim3(256), 0,
+                           h->stream, dA, m, rowptr, N, (int)T, (int)F, dm);
+      GNX_LAUNCH_CHECK();
+      return GNX_OK;
+    }
+  }
   if (F % 4 == 0) {
     int64_t th = N * (T * F / 4);
     hipLaunchKernelGGL(k_pna_agg_bwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr, N,
