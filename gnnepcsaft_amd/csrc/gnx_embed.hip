@@ -222,6 +222,9 @@ static int32_t launch_table_scatter_add(gnx_handle* h, const IdxT* idx, int64_t 
   return GNX_OK;
 }
 
+int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, const int32_t* offsets, int R,
+                           const float* dout, int H, float* dtable);  // gnx_gemm.hip
+
 extern "C" size_t gnx_table_scatter_workspace_bytes(int64_t rows, int32_t R, int32_t H) {
   return gnx_table_scatter_ws_bytes(rows, R, H);
 }
@@ -232,6 +235,11 @@ extern "C" int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t 
   GNX_CHECK_ARG(N == 0 || (idx && dout), "gnx_embed_sum_bwd: NULL array with N>0");
   GNX_CHECK_ARG(offsets[K] == R, "gnx_embed_sum_bwd: offsets[K]=%d != R=%d", offsets[K], R);
   if (N == 0) return GNX_OK;
+  {
+    // large batches: the one-hot x gradient product on the MFMA (exact); small ones: LDS-privatised table adds
+    const int32_t st = gnx_embed_bwd_mfma(h, idx, N, K, offsets, R, dout, H, dtable);
+    if (st <= 0) return st;
+  }
   return launch_table_scatter_add<int64_t>(h, idx, N, K, offsets, R, dout, H, dtable, ws, ws_bytes);
 }
 

@@ -1130,3 +1130,168 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Embedding backward on the matrix cores: dTable[r, :] += sum_n onehot[n, r] * dOut[n, :], where onehot[n, r] counts the
+// features k with offs[k] + idx[n,k] == r ([3P] embedding_dense_backward summed over the K tables of an ogb encoder).
+// It is the weight-gradient contraction over rows with a left operand GENERATED from the integer features (exact: the
+// products are by 0/1), so the 10^8 LDS atomic lane-ops of the table-scatter kernel (~2 clk each) become ~5 GFLOP of MFMA.
+// grid = (row chunks, R tiles of 128, H tiles of 128).
+// ---------------------------------------------------------------------------------------------------------------
+#define EMB_MAX_K 12
+struct embed_bwd_args {
+  const int64_t* idx;  // [N, K]
+  int offs[EMB_MAX_K + 1];
+  int K;
+  const float* Y;  // dOut [N, H]
+  int64_t ldy;
+  int64_t N;
+  int R, H;
+  float* dT;  // [R, H]
+  int64_t rows_per_block;
+};
+
+__global__ void __launch_bounds__(256, 2) k_embed_bwd_mfma(embed_bwd_args g) {
+  __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
+  __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;  // table-row tile
+  const int c0 = blockIdx.z * BN;  // channel tile
+  const int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
+  int64_t r_end = r_begin + g.rows_per_block;
+  if (r_end > g.N) r_end = g.N;
+  if (r_begin >= r_end) return;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int br = tid >> 5;
+  const int bc = (tid & 31) * 4;
+  const int yk = c0 + bc;
+  const bool y_ok = yk < g.H;
+  const int yc = y_ok ? yk : 0;
+  f32x4 ry[4];
+  int fr[4][EMB_MAX_K];  // table rows hit by the 4 batch rows this thread stages (raw loads, used at LDS-store time)
+  int okmask = 0;
+
+  auto load_tile = [&](int64_t r0) {
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t pos = r0 + br + 8 * i;
+      const bool rv = pos < r_end;
+      const int64_t row = rv ? pos : r_begin;
+      ry[i] = *reinterpret_cast<const f32x4*>(g.Y + row * g.ldy + yc);
+#pragma unroll
+      for (int k = 0; k < EMB_MAX_K; ++k) fr[i][k] = (int)g.idx[row * g.K + (k < g.K ? k : 0)];  // unconditional
+      okmask |= rv ? (1 << i) : 0;
+    }
+  };
+
+  int64_t r0 = r_begin;
+  load_tile(r0);
+  while (r0 < r_end) {
+    __syncthreads();
+    {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool rv = (okmask >> i) & 1;
+        f32x4 x = z;
+#pragma unroll
+        for (int k = 0; k < EMB_MAX_K; ++k) {
+          const int span = g.offs[k + 1 <= g.K ? k + 1 : g.K] - g.offs[k < g.K ? k : g.K];
+          const int f = fr[i][k];
+          const int r = g.offs[k < g.K ? k : 0] + f - (n0 + bc);  // position relative to this thread's 4 table rows
+          const bool hit = rv && k < g.K && f >= 0 && f < span;
+          x.x += (hit && r == 0) ? 1.f : 0.f;
+          x.y += (hit && r == 1) ? 1.f : 0.f;
+          x.z += (hit && r == 2) ? 1.f : 0.f;
+          x.w += (hit && r == 3) ? 1.f : 0.f;
+        }
+        const int kr = br + 8 * i;
+        *reinterpret_cast<f32x4*>(&Xs[kr * LDN + bc]) = x;
+        *reinterpret_cast<f32x4*>(&Ys[kr * LDN + bc]) = (rv && y_ok) ? ry[i] : z;
+      }
+    }
+    __syncthreads();
+    r0 += BK;
+    if (r0 < r_end) load_tile(r0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float* p = &Xs[(kk * 8 + 4 * lh) * LDN + wm * 64 + mi * 32 + li];
+        a[mi].x = p[0];
+        a[mi].y = p[LDN];
+        a[mi].z = p[2 * LDN];
+        a[mi].w = p[3 * LDN];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const float* p = &Ys[(kk * 8 + 4 * lh) * LDN + wn * 64 + ni * 32 + li];
+        b[ni].x = p[0];
+        b[ni].y = p[LDN];
+        b[ni].z = p[2 * LDN];
+        b[ni].w = p[3 * LDN];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int gc = c0 + wn * 64 + ni * 32 + li;
+      if (gc >= g.H) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (gr >= g.R) continue;
+        const float v = acc[mi][ni][r];
+        if (v != 0.f) atomicAdd(g.dT + (int64_t)gr * g.H + gc, v);
+      }
+    }
+}
+
+// returns GNX_OK after launching, or 1 if the shape is not eligible (caller falls back to the LDS-atomic kernel)
+int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, const int32_t* offsets, int R,
+                           const float* dout, int H, float* dtable) {
+  if (K > EMB_MAX_K || (H % 4) != 0 || !aligned16(dout) || N < 4096) return 1;
+  const char* e = getenv("GNX_EMBED_BWD_MFMA");
+  if (e && atoi(e) == 0) return 1;
+  embed_bwd_args g;
+  g.idx = idx;
+  for (int k = 0; k <= EMB_MAX_K; ++k) g.offs[k] = offsets[k <= K ? k : K];
+  g.K = K;
+  g.Y = dout;
+  g.ldy = H;
+  g.N = N;
+  g.R = R;
+  g.H = H;
+  g.dT = dtable;
+  const int64_t tiles = gnx_cdiv(R, BN) * gnx_cdiv(H, BN);
+  int64_t chunks = gnx_cdiv(512, tiles);
+  int64_t rows = gnx_cdiv(gnx_cdiv(N, chunks), BK) * BK;
+  if (rows < 128) rows = 128;
+  g.rows_per_block = rows;
+  dim3 grid((unsigned)gnx_cdiv(N, rows), (unsigned)gnx_cdiv(R, BN), (unsigned)gnx_cdiv(H, BN));
+  hipLaunchKernelGGL(k_embed_bwd_mfma, grid, dim3(256), 0, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

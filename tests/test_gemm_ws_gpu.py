@@ -48,3 +48,23 @@ def test_gemm_ws_strided_views_and_guard_rows(gpu_device):
     ref = x[:, F:2 * F].double() @ w[:, F:2 * F].double().T
     assert rel_err(out[:, 2 * F:3 * F], ref) <= TOL
     assert float(out[:, :2 * F].abs().max()) == 0.0 and float(out[:, 3 * F:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,H", [(20000, 128), (9000, 36), (81920, 128)])
+def test_embed_backward_on_mfma(gpu_device, N, H):
+    """Large-batch AtomEncoder backward = one-hot^T x gradient on the matrix cores (exact 0/1 products)."""
+    import numpy as np
+    from gnnepcsaft_amd import nn as gnn
+    from oracle import pyg_restatement as O
+    torch.manual_seed(1)
+    enc_o = O.AtomEncoder(H)
+    enc_n = gnn.AtomEncoder(H)
+    enc_n.load_state_dict(enc_o.state_dict())
+    enc_n.to(gpu_device)
+    rng = np.random.default_rng(N)
+    x = torch.from_numpy(np.stack([rng.integers(0, d, size=N) for d in O.ATOM_FEATURE_DIMS], 1)).long()
+    w = torch.randn(N, H)
+    (enc_o(x) * w).sum().backward()
+    (enc_n(x.to(gpu_device)) * w.to(gpu_device)).sum().backward()
+    for eo, en in zip(enc_o.atom_embedding_list, enc_n.atom_embedding_list):
+        assert rel_err(en.weight.grad, eo.weight.grad) <= TOL
