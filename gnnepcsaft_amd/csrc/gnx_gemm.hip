@@ -511,6 +511,381 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-operand weights-stationary GEMM (the default for the shapes k_gemm_ws covers).
+//
+// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4, so the exact-fp32 kernel above is matrix-core bound at ~55 %
+// of the fp32 peak while HBM idles.  Here every fp32 operand is written EXACTLY as a sum of three bf16 values
+// (x = x1 + x2 + x3: round-to-nearest 8-bit pieces of a 24-bit significand, remainders exact) and the product is
+//     a.b ~= a1.b1 + (a1.b2 + a2.b1 + a2.b2 + a1.b3 + a3.b1)          six v_mfma_f32_32x32x16_bf16 = 6/16 of the
+// fp32-MFMA time.  Every bf16 x bf16 product is exact in fp32 and the accumulation is fp32; the three dropped terms
+// (a2.b3, a3.b2, a3.b3) are <= 2^-25 |a||b|, i.e. below the rounding of the fp32 accumulation itself.  The leading
+// term and the five correction terms use separate accumulators (added once at the end) so the corrections are not
+// absorbed by the rounding of the large partial sum.  Inf operands give NaN (inf - inf in the remainder).
+//
+//   * B (<= 128 x 128 weights) lives in REGISTERS: wave w owns output columns (w&3)*32.., its B fragments for all
+//     eight 16-deep k-slabs are 3 x 8 x 4 = 96 VGPRs, split once per launch.  No LDS traffic for B at all.
+//   * A: 64-row tiles, split when staged: LDS holds three bf16 images [64][128 (+8 pad)] per buffer, two buffers
+//     (102 KB).  Row stride 272 B = 17 x 16 B (odd) -> conflict-free ds_read_b128 fragments.
+//   * per 16-deep slab a wave issues 3 ds_read_b128 and 6 MFMAs; the kernel is HBM-bound (A in, C out).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define W3_BM 64
+#define W3_LDB 272                    // bytes per row of one bf16 image
+#define W3_PIECE (W3_BM * W3_LDB)     // 17408 B
+#define W3_BUF (3 * W3_PIECE)         // 52224 B
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h1 = (__bf16)x[j];
+    const float r1 = x[j] - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    p1[j] = h1;
+    p2[j] = h2;
+    p3[j] = (__bf16)r2;
+  }
+}
+
+template <bool B_TRANS, int EPI>
+__global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nslab = (g.K + 15) >> 4;
+  const int gc = wc + li;
+
+  // ---- this wave's B fragments, split once: lane holds column gc, k = 16 s + 8 lh + j
+  bf16x8 b1[8], b2[8], b3[8];
+  {
+    const bool n_ok = gc < g.N;
+    const int gcc = n_ok ? gc : 0;
+    if (!B_TRANS) {
+      // W[k][n]: stage the zero-filled 128 x 128 image in LDS with coalesced float4 loads (the A buffers are not in
+      // use yet); the fragment below is then a conflict-free column read instead of 64 strided global loads per lane
+      float* wl = reinterpret_cast<float*>(lds3);
+      const int r = tid >> 5, c4 = (tid & 31) * 4;
+      const bool c_ok = c4 < g.N;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = r + 16 * i;
+        f32x4 v = *reinterpret_cast<const f32x4*>(g.B + (int64_t)(rr < g.K ? rr : 0) * g.ldb + (c_ok ? c4 : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(wl + rr * 128 + c4) = (c_ok && rr < g.K) ? v : z;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float x[8];
+      const int k0 = 16 * s + 8 * lh;
+      if (B_TRANS) {  // W[n][k]: 8 consecutive floats of row gc
+        const int ka = (k0 < g.K) ? k0 : 0, kb = (k0 + 4 < g.K) ? k0 + 4 : 0;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(g.B + (int64_t)gcc * g.ldb + ka);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(g.B + (int64_t)gcc * g.ldb + kb);
+        const bool ok0 = n_ok && k0 < g.K, ok1 = n_ok && k0 + 4 < g.K;  // K % 4 == 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = ok0 ? v0[j] : 0.f;
+          x[4 + j] = ok1 ? v1[j] : 0.f;
+        }
+      } else {  // W[k][n]: column gc of 8 consecutive rows of the staged image
+        const float* wl = reinterpret_cast<const float*>(lds3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = wl[(k0 + j) * 128 + gc];
+      }
+      split3(x, b1[s], b2[s], b3[s]);
+    }
+    if (!B_TRANS) __syncthreads();  // the image is overwritten by the first A tile
+  }
+
+  // ---- A tile loader: 16 lanes cover one 512-B row (8 floats each), 32 rows per pass, 2 passes
+  const int ar = tid >> 4, ak = (tid & 15) * 8;
+  const bool ok_lo = ak < g.K, ok_hi = ak + 4 < g.K;
+  const int ak_lo = ok_lo ? ak : 0, ak_hi = ok_hi ? ak + 4 : 0;
+  f32x4 ra[4];
+  int okmask = 0;
+  auto load_a = [&](int tile) {
+    const int64_t m0 = (int64_t)tile * W3_BM;
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gm = m0 + ar + 32 * i;
+      const float* p = g.A + (gm < g.M ? gm : g.M - 1) * g.lda;
+      ra[2 * i] = *reinterpret_cast<const f32x4*>(p + ak_lo);
+      ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + ak_hi);
+      okmask |= (gm < g.M) ? (1 << i) : 0;
+    }
+  };
+  auto store_a = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool row_ok = (okmask >> i) & 1;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = (row_ok && ok_lo) ? ra[2 * i][j] : 0.f;
+        x[4 + j] = (row_ok && ok_hi) ? ra[2 * i + 1][j] : 0.f;
+      }
+      bf16x8 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      unsigned char* q = buf + (ar + 32 * i) * W3_LDB + ak * 2;
+      *reinterpret_cast<bf16x8*>(q) = p1;
+      *reinterpret_cast<bf16x8*>(q + W3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(q + 2 * W3_PIECE) = p3;
+    }
+  };
+
+  const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+
+  int tile = blockIdx.x;  // grid <= ntiles
+  int cur = 0;
+  load_a(tile);
+  store_a(lds3);
+  __syncthreads();
+
+  while (tile < g.ntiles) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < g.ntiles;
+    if (has_next) load_a(next);
+    const int64_t m0 = (int64_t)tile * W3_BM;
+
+    f32x16 acc, corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = 0.f;
+      corr[r] = 0.f;
+    }
+    const unsigned char* ap = lds3 + cur * W3_BUF + (wr + li) * W3_LDB + 16 * lh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nslab) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * s);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + W3_PIECE);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + 2 * W3_PIECE);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[s], corr, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[s], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += corr[r];
+
+    if (m0 + W3_BM <= g.M) {
+      epilogue_tile_full<EPI>(acc, m0 + wr + 4 * lh, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+    } else {
+      int rows[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gr = m0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        rows[r] = gr < g.M ? (int)gr : -1;
+      }
+      epilogue_tile<EPI>(acc, rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+    }
+
+    if (has_next) store_a(lds3 + (cur ^ 1) * W3_BUF);
+    __syncthreads();
+    cur ^= 1;
+    tile = next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-operand tiled GEMM (same contract as k_gemm<.., VEC = true>: multi-segment, row scale, grouped rows; see the
+// split-operand notes at k_gemm_ws3).  Both operands are split into three bf16 images when a K-tile is staged:
+//   LDS  A3[3][128][32 (+8 pad)] bf16, B3[3][128 n][32 k (+8)] bf16 (row stride 80 B = 5 x 16 B, odd -> conflict-free
+//   ds_read_b128), 60 KB per workgroup, two workgroups per CU.  [k][n] weights (NN) are transposed by the loader:
+//   each thread reads 16 k of ONE column (coalesced across lanes) so the image is always k-contiguous.
+// Per 16-deep slab a wave (64 x 64 outputs) reads 12 fragments and issues 24 bf16 MFMAs (fp32: 64 MFMAs, 2x the time
+// each): 6/16 of the matrix-core time of k_gemm.
+// ---------------------------------------------------------------------------------------------------------------
+#define G3_LDB 80                   // bytes per image row
+#define G3_PIECE (128 * G3_LDB)     // 10240 B
+
+template <bool B_TRANS, int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char A3[3 * G3_PIECE];
+  __shared__ __attribute__((aligned(16))) unsigned char B3[3 * G3_PIECE];
+  __shared__ int rid[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  int cls = 0;
+  if (g.tile_info != nullptr) {
+    if ((int)blockIdx.x >= g.ntiles[0]) return;
+    const int p0 = g.tile_info[3 * blockIdx.x], pr = g.tile_info[3 * blockIdx.x + 1];
+    cls = g.tile_info[3 * blockIdx.x + 2];
+    if (tid < BM) rid[tid] = (tid < pr) ? g.row_index[p0 + tid] : -1;
+  } else {
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    if (tid < BM) rid[tid] = (m0 + tid < g.M) ? (int)(m0 + tid) : -1;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2], corr[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        corr[i][j][r] = 0.f;
+      }
+
+  // loaders: A and NT-B: thread = (row tid>>1, 16 k at (tid&1)*16) -> 4 float4; NN-B: thread = (column tid&127,
+  // 16 k at (tid>>7)*16) -> 16 scalar loads, each coalesced over the wave's 64 columns
+  const int lrow = tid >> 1, lkh = (tid & 1) * 16;
+  const int bcol = tid & 127, bkh = (tid >> 7) * 16;
+  const int grow = rid[lrow];
+  const int64_t arow = grow >= 0 ? grow : 0;
+  const int bn_nt = n0 + lrow, bn_nn = n0 + bcol;
+  f32x4 ra[4], rb[4];
+  float rsv = 1.f;
+  int kvalid_a = 0, kvalid_b = 0;  // float4-granular validity bits of the tile in flight (applied at store time)
+
+  auto load_tile = [&](const seg_dev& s, int k0) {
+    const float* sb = s.b + (int64_t)cls * s.cls_stride;
+    const float* ap = s.a + arow * s.lda;
+    kvalid_a = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + lkh + 4 * q;
+      const bool ok = k < s.k;
+      ra[q] = *reinterpret_cast<const f32x4*>(ap + (ok ? k : 0));
+      kvalid_a |= (ok && grow >= 0) ? (1 << q) : 0;
+    }
+    rsv = *(s.rs != nullptr ? s.rs + arow : &c_one);
+    kvalid_b = 0;
+    if (B_TRANS) {
+      const float* bp = sb + (int64_t)(bn_nt < g.N ? bn_nt : 0) * s.ldb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + lkh + 4 * q;
+        const bool ok = k < s.k;
+        rb[q] = *reinterpret_cast<const f32x4*>(bp + (ok ? k : 0));
+        kvalid_b |= (ok && bn_nt < g.N) ? (1 << q) : 0;
+      }
+    } else {
+      const float* bp = sb + (bn_nn < g.N ? bn_nn : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + bkh + 4 * q + j;
+          rb[q][j] = bp[(int64_t)(k < s.k ? k : 0) * s.ldb];
+        }
+        kvalid_b |= (k0 + bkh + 4 * q < s.k && bn_nn < g.N) ? (1 << q) : 0;  // k % 4 == 0: whole groups
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int hgrp = 0; hgrp < 2; ++hgrp) {
+      float xa[8], xb[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xa[4 * q + j] = ((kvalid_a >> (2 * hgrp + q)) & 1) ? ra[2 * hgrp + q][j] * rsv : 0.f;
+          xb[4 * q + j] = ((kvalid_b >> (2 * hgrp + q)) & 1) ? rb[2 * hgrp + q][j] : 0.f;
+        }
+      bf16x8 p1, p2, p3;
+      split3(xa, p1, p2, p3);
+      unsigned char* qa = A3 + lrow * G3_LDB + (lkh + 8 * hgrp) * 2;
+      *reinterpret_cast<bf16x8*>(qa) = p1;
+      *reinterpret_cast<bf16x8*>(qa + G3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(qa + 2 * G3_PIECE) = p3;
+      split3(xb, p1, p2, p3);
+      unsigned char* qb = B3 + (B_TRANS ? lrow * G3_LDB + (lkh + 8 * hgrp) * 2 : bcol * G3_LDB + (bkh + 8 * hgrp) * 2);
+      *reinterpret_cast<bf16x8*>(qb) = p1;
+      *reinterpret_cast<bf16x8*>(qb + G3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(qb + 2 * G3_PIECE) = p3;
+    }
+  };
+
+  int s_idx = 0, k0 = 0;
+  load_tile(g.seg[0], 0);
+  bool more = true;
+  while (more) {
+    __syncthreads();  // previous compute finished reading LDS
+    store_tile();
+    __syncthreads();
+    k0 += BK;
+    if (k0 >= g.seg[s_idx].k) {
+      ++s_idx;
+      k0 = 0;
+    }
+    more = s_idx < g.nseg;
+    if (more) load_tile(g.seg[s_idx], k0);
+
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[mi][p] = *reinterpret_cast<const bf16x8*>(A3 + p * G3_PIECE + (wm * 64 + mi * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[ni][p] = *reinterpret_cast<const bf16x8*>(B3 + p * G3_PIECE + (wn * 64 + ni * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], corr[mi][ni], 0, 0, 0);
+          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], corr[mi][ni], 0, 0, 0);
+          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], corr[mi][ni], 0, 0, 0);
+          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], corr[mi][ni], 0, 0, 0);
+          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], corr[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    int rows[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[r] = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int gc = n0 + wn * 64 + ni * 32 + li;
+      const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] += corr[mi][ni][r];
+      epilogue_tile<EPI>(acc[mi][ni], rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+    }
+  }
+}
+
+template <bool BT, int EPI>
+static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws3<BT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_ws3<BT, EPI>), dim3(grid), dim3(512), 2 * W3_BUF, h->stream, g);
+  return hipGetLastError();
+}
+
 static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, int32_t N, const float* bias,
                               const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
   ws_args g;
@@ -535,7 +910,18 @@ static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, i
   const int grid = g.ntiles < cus ? g.ntiles : cus;
   gnx_prof_scope prof(h, GNX_K_GEMM);
   hipError_t e;
-  if (bt)
+  const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernel (A/B switch, read per call)
+  const bool split = !(split_env && atoi(split_env) == 0);
+  if (split) {
+    if (bt)
+      e = epi == EPI_MASK    ? ws3_launch_one<true, EPI_MASK>(h, g, grid)
+          : epi == EPI_ACCUM ? ws3_launch_one<true, EPI_ACCUM>(h, g, grid)
+                             : ws3_launch_one<true, EPI_PLAIN>(h, g, grid);
+    else
+      e = epi == EPI_MASK    ? ws3_launch_one<false, EPI_MASK>(h, g, grid)
+          : epi == EPI_ACCUM ? ws3_launch_one<false, EPI_ACCUM>(h, g, grid)
+                             : ws3_launch_one<false, EPI_PLAIN>(h, g, grid);
+  } else if (bt)
     e = epi == EPI_MASK    ? ws_launch_one<true, EPI_MASK>(h, g, grid, lds_bytes)
         : epi == EPI_ACCUM ? ws_launch_one<true, EPI_ACCUM>(h, g, grid, lds_bytes)
                            : ws_launch_one<true, EPI_PLAIN>(h, g, grid, lds_bytes);
@@ -688,9 +1074,13 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   }
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
+  const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernels
+  const bool split = vec && !(split_env && atoi(split_env) == 0);
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
-    if (vec)                                                                              \
+    if (split)                                                                            \
+      hipLaunchKernelGGL((k_gemm3<BT, EPI>), grid, dim3(256), 0, h->stream, g);           \
+    else if (vec)                                                                         \
       hipLaunchKernelGGL((k_gemm<BT, EPI, true>), grid, dim3(256), 0, h->stream, g);      \
     else                                                                                  \
       hipLaunchKernelGGL((k_gemm<BT, EPI, false>), grid, dim3(256), 0, h->stream, g);     \

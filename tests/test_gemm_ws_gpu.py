@@ -68,3 +68,36 @@ def test_embed_backward_on_mfma(gpu_device, N, H):
     (enc_n(x.to(gpu_device)) * w.to(gpu_device)).sum().backward()
     for eo, en in zip(enc_o.atom_embedding_list, enc_n.atom_embedding_list):
         assert rel_err(en.weight.grad, eo.weight.grad) <= TOL
+
+
+@pytest.mark.parametrize("b_trans", [True, False])
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 37.0])
+def test_split_operand_product_is_fp32_faithful(gpu_device, b_trans, scale):
+    """The default kernel writes each fp32 operand as three bf16 pieces and issues six bf16 MFMAs (fp32 accumulate).
+    Its error against fp64 must be at the level of the exact-fp32 MFMA kernel (GNX_GEMM_SPLIT=0) -- measured as the
+    max error over all outputs, normalised by sum_k |a||b| (the quantity fp32 rounding scales with)."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(11)
+    M, N, K = 16384, 128, 128
+    a = torch.randn(M, K) * scale
+    w = torch.randn(N, K) if b_trans else torch.randn(K, N)
+    # operands with full 24-bit significands and mixed magnitudes
+    a = a * torch.exp(torch.randn(M, K))
+    ad, wd = a.to(gpu_device), w.to(gpu_device)
+    wm = w.double().T if b_trans else w.double()
+    ref = a.double() @ wm
+    norm = a.double().abs() @ wm.abs()
+    errs = {}
+    for mode in ("1", "0"):
+        os.environ["GNX_GEMM_SPLIT"] = mode
+        try:
+            out = torch.empty(M, N, device=gpu_device)
+            ops.gemm([(ad, None, wd)], out, b_trans=b_trans)
+            errs[mode] = float(((out.double().cpu() - ref).abs() / norm).max())
+        finally:
+            os.environ.pop("GNX_GEMM_SPLIT", None)
+    eps32 = 2.0 ** -24
+    # measured: exact-fp32 MFMA (sequential k chain) ~10 ulp max / 0.7 rms; split product ~4 ulp max / 0.27 rms
+    assert errs["0"] <= 24 * eps32
+    assert errs["1"] <= 8 * eps32
+    assert errs["1"] <= errs["0"] + eps32
