@@ -63,8 +63,8 @@ SIGNATURES = {
     "gnx_degree_classes_workspace_bytes": (_sz, [_i64, _i32]),
     "gnx_degree_classes": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz]),
     "gnx_class_tiles": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
-    "gnx_gemm_grouped": (_i32, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i64, _i32, _vp, _vp, _i64, _vp, _i64,
-                                _i32, _vp, _vp, _vp, _i64]),
+    "gnx_gemm_grouped": (_i32, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i32, _i64, _i32, _vp, _vp, _i64, _vp,
+                                _i64, _i32, _vp, _vp, _vp, _i64]),
     "gnx_gemm_wgrad_grouped": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp,
                                       _i64]),
     "gnx_pna_weff": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),

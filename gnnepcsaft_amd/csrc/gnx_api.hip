@@ -44,6 +44,7 @@ extern "C" int32_t gnx_destroy(gnx_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   (void)hipFree(h->d_flag);
   (void)hipFree(h->d_scratch);
+  for (auto& w : h->wsplit) (void)hipFree(w.buf);
   delete h;
   return GNX_OK;
 }

@@ -16,6 +16,13 @@ struct gnx_handle {
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;
   float* d_scratch = nullptr;  // 4 KiB
+  // split-weight images of the tiled GEMM (k_split_weights -> k_gemm3): one growable buffer per stream that used it
+  struct wsplit_buf {
+    hipStream_t stream;
+    void* buf;
+    size_t bytes;
+  };
+  std::vector<wsplit_buf> wsplit;
   // profiling: bit k of prof_mask = record an event pair around every launch group of kernel id k
   unsigned prof_mask = 0;
   std::vector<hipEvent_t> ev;

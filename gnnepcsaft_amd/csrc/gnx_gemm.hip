@@ -63,6 +63,9 @@ struct gemm_args {
   const int* row_index;
   const int* tile_info;
   const int* ntiles;
+  int ny;  // column tiles (k_gemm3's 1-D grid)
+  const __bf16* bsplit;  // k_gemm3: split weight images (k_split_weights)
+  int Npad, Kpad;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int valid) {
@@ -698,17 +701,69 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Split-operand tiled GEMM (same contract as k_gemm<.., VEC = true>: multi-segment, row scale, grouped rows; see the
-// split-operand notes at k_gemm_ws3).  Both operands are split into three bf16 images when a K-tile is staged:
-//   LDS  A3[3][128][32 (+8 pad)] bf16, B3[3][128 n][32 k (+8)] bf16 (row stride 80 B = 5 x 16 B, odd -> conflict-free
-//   ds_read_b128), 60 KB per workgroup, two workgroups per CU.  [k][n] weights (NN) are transposed by the loader:
-//   each thread reads 16 k of ONE column (coalesced across lanes) so the image is always k-contiguous.
+// split-operand notes at k_gemm_ws3).
+//   * weights: split once per call by k_split_weights into zero-padded bf16 images [class][3][n][k] (either source
+//     layout), so the B tiles are plain 16-B copies global(L2) -> LDS;
+//   * activations: split when a K-tile is staged (the only conversion work left in the loop, ~6 VALU ops / element);
+//   * LDS  A3[3][128][32 (+8 pad)] bf16, B3[3][128 n][32 k (+8)] bf16, row stride 80 B = 5 x 16 B (odd -> conflict-free
+//     ds_read_b128), 60 KB per workgroup, two workgroups per CU.
 // Per 16-deep slab a wave (64 x 64 outputs) reads 12 fragments and issues 24 bf16 MFMAs (fp32: 64 MFMAs, 2x the time
 // each): 6/16 of the matrix-core time of k_gemm.
 // ---------------------------------------------------------------------------------------------------------------
 #define G3_LDB 80                   // bytes per image row
 #define G3_PIECE (128 * G3_LDB)     // 10240 B
 
-template <bool B_TRANS, int EPI>
+// Weight images for k_gemm3: every segment's B (either layout, any class) is split ONCE per call into three bf16
+// images laid out [class][piece][n (padded to 128)][k (each segment padded to 32, segments concatenated)], zero padded:
+// the GEMM workgroups then copy B tiles global -> LDS with no conversion work and no bounds checks.
+struct split_args {
+  seg_dev seg[MAX_SEGS];
+  int koff[MAX_SEGS + 1];  // padded k offset of every segment; koff[nseg] = Kpad
+  int nseg;
+  int N, Npad, Kpad, D;
+  __bf16* out;
+};
+
+template <bool B_TRANS>
+__global__ void __launch_bounds__(256) k_split_weights(split_args g) {
+  const int kgroups = g.Kpad >> 3;
+  const int64_t total = (int64_t)g.D * g.Npad * kgroups;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int c, n, kg;
+  if (B_TRANS) {  // W[n][k]: k fastest
+    kg = (int)(idx % kgroups);
+    n = (int)((idx / kgroups) % g.Npad);
+    c = (int)(idx / ((int64_t)kgroups * g.Npad));
+  } else {  // W[k][n]: n fastest
+    n = (int)(idx % g.Npad);
+    kg = (int)((idx / g.Npad) % kgroups);
+    c = (int)(idx / ((int64_t)kgroups * g.Npad));
+  }
+  const int kk = kg * 8;
+  int si = 0;
+#pragma unroll
+  for (int q = 1; q < MAX_SEGS; ++q) si += (q < g.nseg && kk >= g.koff[q]) ? 1 : 0;
+  const seg_dev& sg = g.seg[si];
+  const int kl = kk - g.koff[si];
+  const float* sb = sg.b + (int64_t)c * sg.cls_stride;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = n < g.N && kl + j < sg.k;
+    const int64_t off = B_TRANS ? (int64_t)n * sg.ldb + kl + j : (int64_t)(kl + j) * sg.ldb + n;
+    x[j] = ok ? sb[ok ? off : 0] : 0.f;
+  }
+  bf16x8 p1, p2, p3;
+  split3(x, p1, p2, p3);
+  const int64_t pstride = (int64_t)g.Npad * g.Kpad;
+  __bf16* o = g.out + ((int64_t)c * 3) * pstride + (int64_t)n * g.Kpad + kk;
+  *reinterpret_cast<bf16x8*>(o) = p1;
+  *reinterpret_cast<bf16x8*>(o + pstride) = p2;
+  *reinterpret_cast<bf16x8*>(o + 2 * pstride) = p3;
+}
+
+template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   __shared__ __attribute__((aligned(16))) unsigned char A3[3 * G3_PIECE];
   __shared__ __attribute__((aligned(16))) unsigned char B3[3 * G3_PIECE];
@@ -719,15 +774,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * BN;
+  // 1-D grid of (row tiles rounded up to 8) x (column tiles): workgroup ids are dealt round-robin to the 8 XCDs, so
+  // the column tiles of one row tile are given ids 8 apart -> same XCD, the shared A rows hit that XCD's L2.
+  const int ny = g.ny;
+  const int group = blockIdx.x / (8 * ny), within = blockIdx.x % (8 * ny);
+  const int row_tile = group * 8 + (within & 7);
+  const int n0 = (within >> 3) * BN;
   int cls = 0;
   if (g.tile_info != nullptr) {
-    if ((int)blockIdx.x >= g.ntiles[0]) return;
-    const int p0 = g.tile_info[3 * blockIdx.x], pr = g.tile_info[3 * blockIdx.x + 1];
-    cls = g.tile_info[3 * blockIdx.x + 2];
+    if (row_tile >= g.ntiles[0]) return;
+    const int p0 = g.tile_info[3 * row_tile], pr = g.tile_info[3 * row_tile + 1];
+    cls = g.tile_info[3 * row_tile + 2];
     if (tid < BM) rid[tid] = (tid < pr) ? g.row_index[p0 + tid] : -1;
   } else {
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t m0 = (int64_t)row_tile * BM;
+    if (m0 >= g.M) return;
     if (tid < BM) rid[tid] = (m0 + tid < g.M) ? (int)(m0 + tid) : -1;
   }
   __syncthreads();
@@ -743,19 +804,20 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
         corr[i][j][r] = 0.f;
       }
 
-  // loaders: A and NT-B: thread = (row tid>>1, 16 k at (tid&1)*16) -> 4 float4; NN-B: thread = (column tid&127,
-  // 16 k at (tid>>7)*16) -> 16 scalar loads, each coalesced over the wave's 64 columns
+  // loaders: thread = (tile row tid>>1, 16 k at (tid&1)*16): A 4 float4 (fp32), B 3 x 2 x 16 B (split images)
   const int lrow = tid >> 1, lkh = (tid & 1) * 16;
-  const int bcol = tid & 127, bkh = (tid >> 7) * 16;
   const int grow = rid[lrow];
   const int64_t arow = grow >= 0 ? grow : 0;
-  const int bn_nt = n0 + lrow, bn_nn = n0 + bcol;
-  f32x4 ra[4], rb[4];
-  float rsv = 1.f;
-  int kvalid_a = 0, kvalid_b = 0;  // float4-granular validity bits of the tile in flight (applied at store time)
+  const int64_t pstride = (int64_t)g.Npad * g.Kpad;  // elements between the three images of one class
+  const __bf16* bq = g.bsplit + (int64_t)cls * 3 * pstride + (int64_t)(n0 + lrow) * g.Kpad + lkh;
+  // A (HBM) is prefetched TWO K-tiles ahead in two alternating register sets (X, Y; the loop is unrolled by two so
+  // no register moves consume a load early); B (L2-resident weights) one tile ahead
+  f32x4 raX[4], raY[4];
+  bf16x8 rb[6];  // B tile of the next stage: 3 images x 16 k, already split and zero padded
+  float rsX = 1.f, rsY = 1.f;
+  int kvX = 0, kvY = 0;  // float4-granular validity bits of the A sets, applied at store time
 
-  auto load_tile = [&](const seg_dev& s, int k0) {
-    const float* sb = s.b + (int64_t)cls * s.cls_stride;
+  auto load_a = [&](const seg_dev& s, int k0, f32x4 (&ra)[4], float& rsv, int& kvalid_a) {
     const float* ap = s.a + arow * s.lda;
     kvalid_a = 0;
 #pragma unroll
@@ -766,70 +828,37 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
       kvalid_a |= (ok && grow >= 0) ? (1 << q) : 0;
     }
     rsv = *(s.rs != nullptr ? s.rs + arow : &c_one);
-    kvalid_b = 0;
-    if (B_TRANS) {
-      const float* bp = sb + (int64_t)(bn_nt < g.N ? bn_nt : 0) * s.ldb;
+  };
+  auto load_b = [&](int kglob) {  // kglob = padded k offset of the tile = 32 * (flattened tile index)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = k0 + lkh + 4 * q;
-        const bool ok = k < s.k;
-        rb[q] = *reinterpret_cast<const f32x4*>(bp + (ok ? k : 0));
-        kvalid_b |= (ok && bn_nt < g.N) ? (1 << q) : 0;
-      }
-    } else {
-      const float* bp = sb + (bn_nn < g.N ? bn_nn : 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = k0 + bkh + 4 * q + j;
-          rb[q][j] = bp[(int64_t)(k < s.k ? k : 0) * s.ldb];
-        }
-        kvalid_b |= (k0 + bkh + 4 * q < s.k && bn_nn < g.N) ? (1 << q) : 0;  // k % 4 == 0: whole groups
-      }
+    for (int p = 0; p < 3; ++p) {
+      rb[2 * p] = *reinterpret_cast<const bf16x8*>(bq + p * pstride + kglob);
+      rb[2 * p + 1] = *reinterpret_cast<const bf16x8*>(bq + p * pstride + kglob + 8);
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](const f32x4 (&ra)[4], const float rsv, const int kvalid_a) {
 #pragma unroll
     for (int hgrp = 0; hgrp < 2; ++hgrp) {
-      float xa[8], xb[8];
+      float xa[8];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
           xa[4 * q + j] = ((kvalid_a >> (2 * hgrp + q)) & 1) ? ra[2 * hgrp + q][j] * rsv : 0.f;
-          xb[4 * q + j] = ((kvalid_b >> (2 * hgrp + q)) & 1) ? rb[2 * hgrp + q][j] : 0.f;
-        }
       bf16x8 p1, p2, p3;
       split3(xa, p1, p2, p3);
       unsigned char* qa = A3 + lrow * G3_LDB + (lkh + 8 * hgrp) * 2;
       *reinterpret_cast<bf16x8*>(qa) = p1;
       *reinterpret_cast<bf16x8*>(qa + G3_PIECE) = p2;
       *reinterpret_cast<bf16x8*>(qa + 2 * G3_PIECE) = p3;
-      split3(xb, p1, p2, p3);
-      unsigned char* qb = B3 + (B_TRANS ? lrow * G3_LDB + (lkh + 8 * hgrp) * 2 : bcol * G3_LDB + (bkh + 8 * hgrp) * 2);
-      *reinterpret_cast<bf16x8*>(qb) = p1;
-      *reinterpret_cast<bf16x8*>(qb + G3_PIECE) = p2;
-      *reinterpret_cast<bf16x8*>(qb + 2 * G3_PIECE) = p3;
+      unsigned char* qb = B3 + lrow * G3_LDB + (lkh + 8 * hgrp) * 2;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(qb + p * G3_PIECE) = rb[2 * p + hgrp];
     }
   };
 
-  int s_idx = 0, k0 = 0;
-  load_tile(g.seg[0], 0);
-  bool more = true;
-  while (more) {
-    __syncthreads();  // previous compute finished reading LDS
-    store_tile();
-    __syncthreads();
-    k0 += BK;
-    if (k0 >= g.seg[s_idx].k) {
-      ++s_idx;
-      k0 = 0;
-    }
-    more = s_idx < g.nseg;
-    if (more) load_tile(g.seg[s_idx], k0);
-
+  auto compute = [&]() {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       bf16x8 a[2][3], b[2][3];
@@ -855,6 +884,40 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
         }
     }
+  };
+
+  // flattened (segment, k0) tile list with two cursors: (s1, k1) = tile being stored, (s2, k2) = newest A prefetch
+  auto advance = [&](int& si, int& ki) {
+    ki += BK;
+    if (ki >= g.seg[si].k) {
+      ++si;
+      ki = 0;
+    }
+  };
+  int s1 = 0, k1 = 0, s2 = 0, k2 = 0, kglob = 0;
+  load_a(g.seg[0], 0, raX, rsX, kvX);
+  load_b(0);
+  advance(s2, k2);
+  if (s2 < g.nseg) load_a(g.seg[s2], k2, raY, rsY, kvY);
+  // one pipeline stage: store tile (s1,k1) from `cur`, refill `cur` with tile +2, fetch B of tile +1, multiply
+  auto stage = [&](f32x4 (&cur)[4], float& rs_cur, int& kv_cur) {
+    __syncthreads();  // previous compute finished reading LDS
+    store_tile(cur, rs_cur, kv_cur);
+    __syncthreads();
+    advance(s1, k1);
+    kglob += BK;
+    if (s1 < g.nseg) {
+      load_b(kglob);
+      advance(s2, k2);
+      if (s2 < g.nseg) load_a(g.seg[s2], k2, cur, rs_cur, kv_cur);
+    }
+    compute();
+  };
+  while (true) {
+    stage(raX, rsX, kvX);
+    if (s1 >= g.nseg) break;
+    stage(raY, rsY, kvY);
+    if (s1 >= g.nseg) break;
   }
 
 #pragma unroll
@@ -1002,8 +1065,37 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
   }
 }
 
+// per-stream growable buffer for the split weight images (grows at most a few times, then steady state)
+static void* wsplit_get(gnx_handle* h, size_t bytes) {
+  gnx_handle::wsplit_buf* w = nullptr;
+  for (auto& e : h->wsplit)
+    if (e.stream == h->stream) w = &e;
+  if (w == nullptr) {
+    h->wsplit.push_back({h->stream, nullptr, 0});
+    w = &h->wsplit.back();
+  }
+  if (bytes > w->bytes) {
+    // kernels queued on this stream may still read the old buffer
+    if (w->buf != nullptr && hipStreamSynchronize(h->stream) != hipSuccess) {
+      gnx_set_error("gnx_gemm: stream synchronize failed while growing the split-weight buffer");
+      return nullptr;
+    }
+    (void)hipFree(w->buf);
+    w->buf = nullptr;
+    w->bytes = 0;
+    size_t cap = bytes + bytes / 2;
+    if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
+    if (hipMalloc(&w->buf, cap) != hipSuccess) {
+      gnx_set_error("gnx_gemm: cannot allocate %zu bytes for the split-weight images", cap);
+      return nullptr;
+    }
+    w->bytes = cap;
+  }
+  return w->buf;
+}
+
 static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
-                           int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
+                           int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
                            int64_t ldc, int32_t flags, const int32_t* row_index, const int32_t* tile_info,
                            const int32_t* ntiles, int64_t max_tiles) {
   GNX_CHECK_ARG(h && segs && C, "gnx_gemm: NULL argument");
@@ -1066,6 +1158,8 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   g.ntiles = ntiles;
   const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
+  g.ny = (int)grid.y;
+  const dim3 grid3((unsigned)(gnx_cdiv((int64_t)grid.x, 8) * 8 * grid.y));
   gnx_prof_scope prof(h, GNX_K_GEMM);
   bool vec = true;
   {
@@ -1076,10 +1170,37 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
   const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernels
   const bool split = vec && !(split_env && atoi(split_env) == 0);
+  if (split) {
+    split_args sa;
+    for (int q = 0; q < MAX_SEGS; ++q) sa.seg[q] = g.seg[q];
+    int kp = 0;
+    for (int q = 0; q < nseg; ++q) {
+      sa.koff[q] = kp;
+      kp += (int)gnx_cdiv((int64_t)g.seg[q].k, BK) * BK;
+    }
+    for (int q = nseg; q <= MAX_SEGS; ++q) sa.koff[q] = kp;
+    sa.nseg = nseg;
+    sa.N = N;
+    sa.Npad = (int)gnx_cdiv((int64_t)N, BN) * BN;
+    sa.Kpad = kp;
+    sa.D = num_classes > 0 ? num_classes : 1;
+    const size_t need = (size_t)sa.D * 3 * sa.Npad * sa.Kpad * sizeof(__bf16);
+    void* buf = wsplit_get(h, need);
+    if (buf == nullptr) return GNX_E_HIP;
+    sa.out = reinterpret_cast<__bf16*>(buf);
+    const int64_t items = (int64_t)sa.D * sa.Npad * (sa.Kpad / 8);
+    if (bt)
+      hipLaunchKernelGGL(k_split_weights<true>, dim3((unsigned)gnx_cdiv(items, 256)), dim3(256), 0, h->stream, sa);
+    else
+      hipLaunchKernelGGL(k_split_weights<false>, dim3((unsigned)gnx_cdiv(items, 256)), dim3(256), 0, h->stream, sa);
+    g.bsplit = sa.out;
+    g.Npad = sa.Npad;
+    g.Kpad = sa.Kpad;
+  }
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
     if (split)                                                                            \
-      hipLaunchKernelGGL((k_gemm3<BT, EPI>), grid, dim3(256), 0, h->stream, g);           \
+      hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);              \
     else if (vec)                                                                         \
       hipLaunchKernelGGL((k_gemm<BT, EPI, true>), grid, dim3(256), 0, h->stream, g);      \
     else                                                                                  \
@@ -1107,16 +1228,17 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
 
 extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
                             const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
-  return gemm_launch(h, nseg, segs, nullptr, M, N, bias, mask, ldmask, C, ldc, flags, nullptr, nullptr, nullptr, 0);
+  return gemm_launch(h, nseg, segs, nullptr, 1, M, N, bias, mask, ldmask, C, ldc, flags, nullptr, nullptr, nullptr, 0);
 }
 
 extern "C" int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
-                                    int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask,
-                                    float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
+                                    int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
+                                    int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
                                     const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles) {
   GNX_CHECK_ARG(cls_strides && row_index && tile_info && ntiles && max_tiles > 0, "gnx_gemm_grouped: NULL argument");
-  return gemm_launch(h, nseg, segs, cls_strides, M, N, bias, mask, ldmask, C, ldc, flags, row_index, tile_info, ntiles,
-                     max_tiles);
+  GNX_CHECK_ARG(num_classes >= 1 && num_classes <= 4096, "gnx_gemm_grouped: num_classes=%d not in [1,4096]", num_classes);
+  return gemm_launch(h, nseg, segs, cls_strides, num_classes, M, N, bias, mask, ldmask, C, ldc, flags, row_index,
+                     tile_info, ntiles, max_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

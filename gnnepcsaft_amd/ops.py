@@ -277,7 +277,7 @@ def gemm_grouped(segs: Sequence[GSeg], out: torch.Tensor, dc: DegreeClasses, *, 
         strides[i] = stride
     flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_B_TRANS if b_trans else 0)
     mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
-    check(_lib.load().gnx_gemm_grouped(handle(out.device), len(segs), arr, strides, M, N, _ptr(bias), mp, ldm, cptr,
+    check(_lib.load().gnx_gemm_grouped(handle(out.device), len(segs), arr, strides, dc.D, M, N, _ptr(bias), mp, ldm, cptr,
                                        ldc, flags, dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(),
                                        dc.max_tiles))
     return out

@@ -174,11 +174,12 @@ int32_t gnx_class_tiles(gnx_handle* h, const int32_t* cls_ptr, int32_t D, int32_
                         int32_t* ntiles);
 /* gnx_gemm over class tiles: workgroup t handles rows row_index[tile_info[3t] .. +tile_info[3t+1]) (gathered A rows,
  * scattered C rows) and reads segment s's B at b + class * cls_strides[s] (cls_strides: HOST int64[nseg], 0 = shared).
+ * num_classes = number of weight sets behind every non-zero stride (class ids in tile_info are < num_classes).
  * Launches max_tiles workgroups; those >= *ntiles exit. */
-int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides, int64_t M,
-                         int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc,
-                         int32_t flags, const int32_t* row_index, const int32_t* tile_info, const int32_t* ntiles,
-                         int64_t max_tiles);
+int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                         int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
+                         int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
+                         const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles);
 /* per-class weight gradient: dW_cls[c] (stride dw_cls_stride) += sum over the rows of class c of dC[row]^T A[row]. */
 int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M,
                                int32_t N, int32_t K, float* dW_cls, int64_t lddw, int64_t dw_cls_stride,
