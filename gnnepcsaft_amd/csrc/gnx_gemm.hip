@@ -66,6 +66,8 @@ struct gemm_args {
   int ny;  // column tiles (k_gemm3's 1-D grid)
   const __bf16* bsplit;  // k_gemm3: split weight images (k_split_weights)
   int Npad, Kpad;
+  int koff[MAX_SEGS];  // padded k offset of every segment inside the images
+  int steps;           // K-tiles per output tile
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p, bool vec, int valid) {
@@ -109,7 +111,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const int (&row
   }
 }
 
-__device__ __constant__ float c_one = 1.0f;  // row scale of segments that have none (pointer-select, no branch)
+// Row scale of segments that have none (pointer-select, no branch).  A __device__ (global address space) variable on
+// purpose: selecting between a kernel-argument pointer and a __constant__ address yields a GENERIC pointer, i.e. a
+// flat_load, and one outstanding flat load turns every counted s_waitcnt vmcnt(N) of the loop into vmcnt(0).
+__device__ float c_one = 1.0f;
 
 // VEC = every operand is 16-B aligned with leading dimensions / k / class strides multiples of 4 (always true for the
 // model's shapes): loads are unconditional float4 from clamped addresses + a select, so all 8 loads of a K-tile are in
@@ -711,11 +716,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
 // each): 6/16 of the matrix-core time of k_gemm.
 // ---------------------------------------------------------------------------------------------------------------
 #define G3_LDB 80                   // bytes per image row
-#define G3_PIECE (128 * G3_LDB)     // 10240 B
+#define G3_PIECE (128 * G3_LDB)     // 10240 B: one bf16 image of a 128 x 32 K-tile
+#define G3_OP (3 * G3_PIECE)        // the three images of one operand
 
 // Weight images for k_gemm3: every segment's B (either layout, any class) is split ONCE per call into three bf16
-// images laid out [class][piece][n (padded to 128)][k (each segment padded to 32, segments concatenated)], zero padded:
-// the GEMM workgroups then copy B tiles global -> LDS with no conversion work and no bounds checks.
+// images, zero padded (n to 128, every segment's k to 32, segments concatenated) and stored TILE-MAJOR
+// [class][n tile][k tile][piece][128][32]: a workgroup copies the 24 KB of a K-tile global -> LDS with fully coalesced
+// 16-byte loads (8 cache lines per wave instruction), no conversion work and no bounds checks.
 struct split_args {
   seg_dev seg[MAX_SEGS];
   int koff[MAX_SEGS + 1];  // padded k offset of every segment; koff[nseg] = Kpad
@@ -756,17 +763,29 @@ __global__ void __launch_bounds__(256) k_split_weights(split_args g) {
   }
   bf16x8 p1, p2, p3;
   split3(x, p1, p2, p3);
-  const int64_t pstride = (int64_t)g.Npad * g.Kpad;
-  __bf16* o = g.out + ((int64_t)c * 3) * pstride + (int64_t)n * g.Kpad + kk;
+  // tile-major: [class][n tile][k tile][piece][128 n][32 k] -> the 24 KB of one (n tile, k tile) are contiguous
+  const int NT = g.Npad / BN, KT = g.Kpad / BK;
+  __bf16* o = g.out + ((((int64_t)c * NT + n / BN) * KT + kk / BK) * 3) * (BN * BK) + (n % BN) * BK + (kk % BK);
   *reinterpret_cast<bf16x8*>(o) = p1;
-  *reinterpret_cast<bf16x8*>(o + pstride) = p2;
-  *reinterpret_cast<bf16x8*>(o + 2 * pstride) = p3;
+  *reinterpret_cast<bf16x8*>(o + BN * BK) = p2;
+  *reinterpret_cast<bf16x8*>(o + 2 * BN * BK) = p3;
 }
 
+// Persistent workgroups (two per CU): workgroup w walks the virtual tile ids w, w + G, w + 2G, ...  A virtual id v maps
+// to (row tile, column tile) so that the column tiles of one row tile get ids 8 apart = the same XCD (ids are dealt
+// round-robin to the 8 XCDs and G % 8 == 0): the shared A rows hit that XCD's L2.  Row tiles grow with v, so the first
+// invalid tile ends the walk.  The loads of the next tile (its row ids, then its first K-tile) are issued while the
+// current tile is still multiplying, so a workgroup waits on a cold pipeline only once.
+//
+// Measured dead ends on MI355X (kept out of the code, recorded here): a 512-thread double-buffered variant with
+// hand-counted inline-asm loads, the same with the loads interleaved between MFMAs, and a loader/multiply
+// wave-specialised variant were all correct and all 3-20 % SLOWER than this two-barrier form; their phase ablations
+// were additive (load + split + MFMA time), i.e. the phases did not overlap inside one workgroup whatever the
+// structure, while two independent workgroups per CU do overlap each other.
 template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
-  __shared__ __attribute__((aligned(16))) unsigned char A3[3 * G3_PIECE];
-  __shared__ __attribute__((aligned(16))) unsigned char B3[3 * G3_PIECE];
+  __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
+  __shared__ __attribute__((aligned(16))) unsigned char B3[G3_OP];
   __shared__ int rid[BM];
 
   const int tid = threadIdx.x;
@@ -774,88 +793,121 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  // 1-D grid of (row tiles rounded up to 8) x (column tiles): workgroup ids are dealt round-robin to the 8 XCDs, so
-  // the column tiles of one row tile are given ids 8 apart -> same XCD, the shared A rows hit that XCD's L2.
-  const int ny = g.ny;
-  const int group = blockIdx.x / (8 * ny), within = blockIdx.x % (8 * ny);
-  const int row_tile = group * 8 + (within & 7);
-  const int n0 = (within >> 3) * BN;
-  int cls = 0;
-  if (g.tile_info != nullptr) {
-    if (row_tile >= g.ntiles[0]) return;
-    const int p0 = g.tile_info[3 * row_tile], pr = g.tile_info[3 * row_tile + 1];
-    cls = g.tile_info[3 * row_tile + 2];
-    if (tid < BM) rid[tid] = (tid < pr) ? g.row_index[p0 + tid] : -1;
-  } else {
-    const int64_t m0 = (int64_t)row_tile * BM;
-    if (m0 >= g.M) return;
-    if (tid < BM) rid[tid] = (m0 + tid < g.M) ? (int)(m0 + tid) : -1;
+  // loader geometry.  A: 8 lanes cover one 128-byte row segment (one cache line), 32 rows per pass, 4 passes: every
+  // wave instruction touches 8 whole lines (two lanes per row = 32 lines per instruction, each line hit by four
+  // instructions, was texture-path bound).  B: the 24 KB K-tile of the tile-major image is read linearly.
+  const int lrow = tid >> 3, lk4 = (tid & 7) * 4;
+  const int NT = g.Npad / BN, KT = g.Kpad / BK;
+
+  const int ny = g.ny, G = gridDim.x;
+  const bool grouped = g.tile_info != nullptr;
+  const int nrt = grouped ? g.ntiles[0] : (int)((g.M + BM - 1) / BM);
+  auto row_tile_of = [&](int v) { return (v / (8 * ny)) * 8 + ((v % (8 * ny)) & 7); };
+  auto n0_of = [&](int v) { return ((v % (8 * ny)) >> 3) * BN; };
+
+  // tile context: cur = tile being multiplied, nxt = the following one (row ids in flight), ti2 = tile_info of the
+  // one after that (two-level dependency tile_info -> row_index, each level fetched one tile ahead)
+  int v_cur = blockIdx.x;
+  if (row_tile_of(v_cur) >= nrt) return;
+  int grow[4], cls, n0, grow_n[4] = {-1, -1, -1, -1}, ridt_n = -1, cls_n = 0, n0_n = 0, ti2_p0 = 0, ti2_pr = 0, ti2_cls = 0;
+  bool valid_n;
+  auto fetch_ti = [&](int v, int& p0, int& pr, int& c) {  // tile_info triple (clamped; callers check validity)
+    const int rt = row_tile_of(v);
+    const int rtc = rt < nrt ? rt : 0;
+    p0 = g.tile_info[3 * rtc];
+    pr = g.tile_info[3 * rtc + 1];
+    c = g.tile_info[3 * rtc + 2];
+  };
+  auto fetch_rows = [&](int v, int p0, int pr, int c, int (&gr)[4], int& rt_id, int& cl) {
+    const int t = tid < BM ? tid : 0;
+    if (grouped) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = lrow + 32 * q;
+        gr[q] = g.row_index[p0 + (r < pr ? r : 0)];
+        gr[q] = r < pr ? gr[q] : -1;
+      }
+      rt_id = g.row_index[p0 + (t < pr ? t : 0)];
+      rt_id = t < pr ? rt_id : -1;
+      cl = c;
+    } else {
+      const int64_t m0 = (int64_t)row_tile_of(v) * BM;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gr[q] = (m0 + lrow + 32 * q < g.M) ? (int)(m0 + lrow + 32 * q) : -1;
+      rt_id = (m0 + t < g.M) ? (int)(m0 + t) : -1;
+      cl = 0;
+    }
+  };
+  {
+    int p0 = 0, pr = 0, c = 0, rt_id;
+    if (grouped) fetch_ti(v_cur, p0, pr, c);
+    fetch_rows(v_cur, p0, pr, c, grow, rt_id, cls);
+    n0 = n0_of(v_cur);
+    if (tid < BM) rid[tid] = rt_id;
+    valid_n = row_tile_of(v_cur + G) < nrt;
+    if (valid_n) {
+      if (grouped) fetch_ti(v_cur + G, p0, pr, c);
+      fetch_rows(v_cur + G, p0, pr, c, grow_n, ridt_n, cls_n);
+      n0_n = n0_of(v_cur + G);
+    }
+    if (grouped) fetch_ti(v_cur + 2 * G, ti2_p0, ti2_pr, ti2_cls);
   }
   __syncthreads();
 
-  f32x16 acc[2][2], corr[2][2];
+  // one accumulator per 32x32 tile (the register budget of a 128x128 tile does not allow k_gemm_ws3's separate
+  // correction accumulators): 6 roundings per 16 k instead of the 16 of the fp32 MFMA chain
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[i][j][r] = 0.f;
-        corr[i][j][r] = 0.f;
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // loaders: thread = (tile row tid>>1, 16 k at (tid&1)*16): A 4 float4 (fp32), B 3 x 2 x 16 B (split images)
-  const int lrow = tid >> 1, lkh = (tid & 1) * 16;
-  const int grow = rid[lrow];
-  const int64_t arow = grow >= 0 ? grow : 0;
-  const int64_t pstride = (int64_t)g.Npad * g.Kpad;  // elements between the three images of one class
-  const __bf16* bq = g.bsplit + (int64_t)cls * 3 * pstride + (int64_t)(n0 + lrow) * g.Kpad + lkh;
-  // A (HBM) is prefetched TWO K-tiles ahead in two alternating register sets (X, Y; the loop is unrolled by two so
-  // no register moves consume a load early); B (L2-resident weights) one tile ahead
-  f32x4 raX[4], raY[4];
-  bf16x8 rb[6];  // B tile of the next stage: 3 images x 16 k, already split and zero padded
-  float rsX = 1.f, rsY = 1.f;
-  int kvX = 0, kvY = 0;  // float4-granular validity bits of the A sets, applied at store time
+  f32x4 ra[4];   // A K-tile of the next stage (fp32, split at store time): rows lrow + 32 q, k lk4..+3
+  f32x4 rb[6];   // B K-tile of the next stage: six 16-byte words of the contiguous [3][128][32] bf16 block
+  int kvalid_a = 0;  // per-pass validity bits of ra, applied at store time
 
-  auto load_a = [&](const seg_dev& s, int k0, f32x4 (&ra)[4], float& rsv, int& kvalid_a) {
-    const float* ap = s.a + arow * s.lda;
+  auto load_ab = [&](int s_i, int k0, const int (&gr)[4], int cl, int nn0) {
+    const seg_dev& s = g.seg[s_i];
+    const int k = k0 + lk4;
+    const bool k_ok = k < s.k;
+    const float* ap = s.a + (k_ok ? k : 0);
     kvalid_a = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int k = k0 + lkh + 4 * q;
-      const bool ok = k < s.k;
-      ra[q] = *reinterpret_cast<const f32x4*>(ap + (ok ? k : 0));
-      kvalid_a |= (ok && grow >= 0) ? (1 << q) : 0;
+      const int64_t arow = gr[q] >= 0 ? gr[q] : 0;
+      ra[q] = *reinterpret_cast<const f32x4*>(ap + arow * s.lda);
+      kvalid_a |= (k_ok && gr[q] >= 0) ? (1 << q) : 0;
     }
-    rsv = *(s.rs != nullptr ? s.rs + arow : &c_one);
-  };
-  auto load_b = [&](int kglob) {  // kglob = padded k offset of the tile = 32 * (flattened tile index)
+    const __bf16* bq = g.bsplit + ((((int64_t)cl * NT + nn0 / BN) * KT + (g.koff[s_i] + k0) / BK) * 3) * (BN * BK) + tid * 8;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      rb[2 * p] = *reinterpret_cast<const bf16x8*>(bq + p * pstride + kglob);
-      rb[2 * p + 1] = *reinterpret_cast<const bf16x8*>(bq + p * pstride + kglob + 8);
-    }
+    for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bq + j * 2048);
   };
 
-  auto store_tile = [&](const f32x4 (&ra)[4], const float rsv, const int kvalid_a) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;  // 8-byte LDS word (four bf16)
+  auto store_tile = [&]() {
 #pragma unroll
-    for (int hgrp = 0; hgrp < 2; ++hgrp) {
+    for (int h = 0; h < 2; ++h) {  // rows (lrow + 64 h, lrow + 64 h + 32): four k each -> one split3 of 8 values
       float xa[8];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          xa[4 * q + j] = ((kvalid_a >> (2 * hgrp + q)) & 1) ? ra[2 * hgrp + q][j] * rsv : 0.f;
-      bf16x8 p1, p2, p3;
-      split3(xa, p1, p2, p3);
-      unsigned char* qa = A3 + lrow * G3_LDB + (lkh + 8 * hgrp) * 2;
-      *reinterpret_cast<bf16x8*>(qa) = p1;
-      *reinterpret_cast<bf16x8*>(qa + G3_PIECE) = p2;
-      *reinterpret_cast<bf16x8*>(qa + 2 * G3_PIECE) = p3;
-      unsigned char* qb = B3 + lrow * G3_LDB + (lkh + 8 * hgrp) * 2;
+        for (int j = 0; j < 4; ++j) xa[4 * q + j] = ((kvalid_a >> (2 * h + q)) & 1) ? ra[2 * h + q][j] : 0.f;
+      bf16x8 pc[3];
+      split3(xa, pc[0], pc[1], pc[2]);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(qb + p * G3_PIECE) = rb[2 * p + hgrp];
+      for (int p = 0; p < 3; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+        unsigned char* qa = A3 + p * G3_PIECE + (lrow + 64 * h) * G3_LDB + lk4 * 2;
+        *reinterpret_cast<f32x2*>(qa) = f32x2{w.x, w.y};
+        *reinterpret_cast<f32x2*>(qa + 32 * G3_LDB) = f32x2{w.z, w.w};
+      }
     }
+    // B: chunk c = j * 256 + tid of the contiguous [piece][128][32] block -> piece j / 2, row (j & 1) * 64 + tid / 4
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      *reinterpret_cast<f32x4*>(B3 + (j >> 1) * G3_PIECE + ((j & 1) * 64 + (tid >> 2)) * G3_LDB + (tid & 3) * 16) = rb[j];
   };
 
   auto compute = [&]() {
@@ -876,63 +928,79 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], corr[mi][ni], 0, 0, 0);
-          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], corr[mi][ni], 0, 0, 0);
-          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], corr[mi][ni], 0, 0, 0);
-          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], corr[mi][ni], 0, 0, 0);
-          corr[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], corr[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
         }
     }
   };
 
-  // flattened (segment, k0) tile list with two cursors: (s1, k1) = tile being stored, (s2, k2) = newest A prefetch
-  auto advance = [&](int& si, int& ki) {
-    ki += BK;
-    if (ki >= g.seg[si].k) {
-      ++si;
-      ki = 0;
-    }
-  };
-  int s1 = 0, k1 = 0, s2 = 0, k2 = 0, kglob = 0;
-  load_a(g.seg[0], 0, raX, rsX, kvX);
-  load_b(0);
-  advance(s2, k2);
-  if (s2 < g.nseg) load_a(g.seg[s2], k2, raY, rsY, kvY);
-  // one pipeline stage: store tile (s1,k1) from `cur`, refill `cur` with tile +2, fetch B of tile +1, multiply
-  auto stage = [&](f32x4 (&cur)[4], float& rs_cur, int& kv_cur) {
-    __syncthreads();  // previous compute finished reading LDS
-    store_tile(cur, rs_cur, kv_cur);
-    __syncthreads();
-    advance(s1, k1);
-    kglob += BK;
-    if (s1 < g.nseg) {
-      load_b(kglob);
-      advance(s2, k2);
-      if (s2 < g.nseg) load_a(g.seg[s2], k2, cur, rs_cur, kv_cur);
-    }
-    compute();
-  };
-  while (true) {
-    stage(raX, rsX, kvX);
-    if (s1 >= g.nseg) break;
-    stage(raY, rsY, kvY);
-    if (s1 >= g.nseg) break;
-  }
-
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    int rows[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rows[r] = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+  // bias of the current tile's columns (fetched at the tile switch, consumed in the epilogue)
+  float bv[2];
+  auto fetch_bias = [&](int nn0) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      const int gc = n0 + wn * 64 + ni * 32 + li;
-      const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] += corr[mi][ni][r];
-      epilogue_tile<EPI>(acc[mi][ni], rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+      const int gc = nn0 + wn * 64 + ni * 32 + li;
+      bv[ni] = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
     }
+  };
+  fetch_bias(n0);
+
+  int s1 = 0, k1 = 0;  // (segment, k) of the K-tile held in ra / rb
+  load_ab(0, 0, grow, cls, n0);
+  while (true) {
+    __syncthreads();  // previous multiply finished reading LDS
+    store_tile();
+    __syncthreads();
+    // advance to the next K-tile; past the last segment it is the next tile's first K-tile
+    k1 += BK;
+    if (k1 >= g.seg[s1].k) {
+      ++s1;
+      k1 = 0;
+    }
+    const bool last = s1 >= g.nseg;
+    if (!last) {
+      load_ab(s1, k1, grow, cls, n0);
+    } else if (valid_n) {
+      load_ab(0, 0, grow_n, cls_n, n0_n);
+    }
+    compute();
+    if (!last) continue;
+
+    // ---- tile finished: epilogue, then switch to the next tile's context
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      int rows[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rows[r] = rid[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int gc = n0 + wn * 64 + ni * 32 + li;
+        epilogue_tile<EPI>(acc[mi][ni], rows, gc, g.N, bv[ni], g.relu, g.mask, g.ldmask, g.C, g.ldc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      }
+    }
+    if (!valid_n) break;
+    __syncthreads();  // every wave has read rid[] of the finished tile
+    v_cur += G;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) grow[q] = grow_n[q];
+    cls = cls_n;
+    n0 = n0_n;
+    if (tid < BM) rid[tid] = ridt_n;  // ordered before its first use by the two barriers of the next stage
+    fetch_bias(n0);
+    s1 = 0;
+    k1 = 0;
+    valid_n = row_tile_of(v_cur + G) < nrt;
+    if (valid_n) {
+      fetch_rows(v_cur + G, ti2_p0, ti2_pr, ti2_cls, grow_n, ridt_n, cls_n);
+      n0_n = n0_of(v_cur + G);
+    }
+    if (grouped) fetch_ti(v_cur + 2 * G, ti2_p0, ti2_pr, ti2_cls);
   }
 }
 
@@ -1159,7 +1227,16 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   g.ny = (int)grid.y;
-  const dim3 grid3((unsigned)(gnx_cdiv((int64_t)grid.x, 8) * 8 * grid.y));
+  // k_gemm3: persistent workgroups, two per CU, count a multiple of 8 * ny (the XCD-aware tile walk needs it)
+  unsigned g3 = (unsigned)(gnx_cdiv((int64_t)grid.x, 8) * 8 * grid.y);
+  {
+    const unsigned unit = 8u * grid.y;
+    unsigned slots = 2u * (unsigned)(h->num_cus > 0 ? h->num_cus : 256);
+    slots = slots / unit * unit;
+    if (slots < unit) slots = unit;
+    if (g3 > slots) g3 = slots;
+  }
+  const dim3 grid3(g3);
   gnx_prof_scope prof(h, GNX_K_GEMM);
   bool vec = true;
   {
@@ -1169,7 +1246,12 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
   const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernels
-  const bool split = vec && !(split_env && atoi(split_env) == 0);
+  int ksteps = 0;
+  for (int q = 0; q < nseg; ++q) ksteps += (int)gnx_cdiv((int64_t)g.seg[q].k, BK);
+  bool any_rs = false;
+  for (int q = 0; q < nseg; ++q) any_rs = any_rs || g.seg[q].rs != nullptr;
+  // row-scaled segments (the 4-segment post-layer-0 of hub-heavy batches) stay on the fp32-MFMA kernel
+  const bool split = vec && ksteps >= 2 && !any_rs && !(split_env && atoi(split_env) == 0);
   if (split) {
     split_args sa;
     for (int q = 0; q < MAX_SEGS; ++q) sa.seg[q] = g.seg[q];
@@ -1196,12 +1278,14 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     g.bsplit = sa.out;
     g.Npad = sa.Npad;
     g.Kpad = sa.Kpad;
+    for (int q = 0; q < MAX_SEGS; ++q) g.koff[q] = sa.koff[q];
+    g.steps = sa.Kpad / BK;
   }
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
-    if (split)                                                                            \
+    if (split) {                                                                          \
       hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);              \
-    else if (vec)                                                                         \
+    } else if (vec)                                                                       \
       hipLaunchKernelGGL((k_gemm<BT, EPI, true>), grid, dim3(256), 0, h->stream, g);      \
     else                                                                                  \
       hipLaunchKernelGGL((k_gemm<BT, EPI, false>), grid, dim3(256), 0, h->stream, g);     \
