@@ -566,6 +566,50 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   const int nslab = (g.K + 15) >> 4;
   const int gc = wc + li;
 
+  // ---- A tile loader: 32 lanes cover one 512-B row with consecutive float4 (whole cache lines per wave instruction:
+  // a wave load touches 2 rows = 8 lines; 16 lanes x 2 float4 per row touched 16 half-used lines per instruction and
+  // was bound by line operations in the texture path), 16 rows per pass, 4 passes
+  const int ar = tid >> 5, ak = (tid & 31) * 4;
+  const bool ak_ok = ak < g.K;
+  const int akc = ak_ok ? ak : 0;
+  f32x4 ra[4];
+  int okmask = 0;
+  auto load_a = [&](int tile) {
+    const int64_t m0 = (int64_t)tile * W3_BM;
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t gm = m0 + ar + 16 * i;
+      ra[i] = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
+      okmask |= (ak_ok && gm < g.M) ? (1 << i) : 0;
+    }
+  };
+  typedef __attribute__((ext_vector_type(2))) float f32x2;  // 8-byte LDS word (four bf16)
+  auto store_a = [&](unsigned char* buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // rows ar + 32 h and ar + 32 h + 16: four k each -> one split3 of 8 values
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[4 * q + j] = ((okmask >> (2 * h + q)) & 1) ? ra[2 * h + q][j] : 0.f;
+      bf16x8 pc[3];
+      split3(x, pc[0], pc[1], pc[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+        unsigned char* q = buf + p * W3_PIECE + (ar + 32 * h) * W3_LDB + ak * 2;
+        *reinterpret_cast<f32x2*>(q) = f32x2{w.x, w.y};
+        *reinterpret_cast<f32x2*>(q + 16 * W3_LDB) = f32x2{w.z, w.w};
+      }
+    }
+  };
+
+  const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+  int tile = blockIdx.x;  // grid <= ntiles
+  int cur = 0;
+  load_a(tile);  // in flight while the weight fragments are fetched and split
+
   // ---- this wave's B fragments, split once: lane holds column gc, k = 16 s + 8 lh + j
   bf16x8 b1[8], b2[8], b3[8];
   {
@@ -610,48 +654,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
     if (!B_TRANS) __syncthreads();  // the image is overwritten by the first A tile
   }
 
-  // ---- A tile loader: 16 lanes cover one 512-B row (8 floats each), 32 rows per pass, 2 passes
-  const int ar = tid >> 4, ak = (tid & 15) * 8;
-  const bool ok_lo = ak < g.K, ok_hi = ak + 4 < g.K;
-  const int ak_lo = ok_lo ? ak : 0, ak_hi = ok_hi ? ak + 4 : 0;
-  f32x4 ra[4];
-  int okmask = 0;
-  auto load_a = [&](int tile) {
-    const int64_t m0 = (int64_t)tile * W3_BM;
-    okmask = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t gm = m0 + ar + 32 * i;
-      const float* p = g.A + (gm < g.M ? gm : g.M - 1) * g.lda;
-      ra[2 * i] = *reinterpret_cast<const f32x4*>(p + ak_lo);
-      ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + ak_hi);
-      okmask |= (gm < g.M) ? (1 << i) : 0;
-    }
-  };
-  auto store_a = [&](unsigned char* buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool row_ok = (okmask >> i) & 1;
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = (row_ok && ok_lo) ? ra[2 * i][j] : 0.f;
-        x[4 + j] = (row_ok && ok_hi) ? ra[2 * i + 1][j] : 0.f;
-      }
-      bf16x8 p1, p2, p3;
-      split3(x, p1, p2, p3);
-      unsigned char* q = buf + (ar + 32 * i) * W3_LDB + ak * 2;
-      *reinterpret_cast<bf16x8*>(q) = p1;
-      *reinterpret_cast<bf16x8*>(q + W3_PIECE) = p2;
-      *reinterpret_cast<bf16x8*>(q + 2 * W3_PIECE) = p3;
-    }
-  };
-
-  const float bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
-
-  int tile = blockIdx.x;  // grid <= ntiles
-  int cur = 0;
-  load_a(tile);
   store_a(lds3);
   __syncthreads();
 
