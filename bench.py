@@ -165,10 +165,14 @@ def main():
     ops.check_range(dev)
     # per-kernel durations: HIP events around every launch of the named kernels on their launch stream, over `steps`
     # eager steps of the same workload (event records cannot live inside the replayed graph)
+    # The weight-gradient stream is switched off for these measurement steps: overlapped wgrad kernels share HBM with
+    # the backward scatter kernel and would double its event-measured duration (a scheduling effect, not the kernel).
+    ops.set_wgrad_side_stream(False)
     ops.prof_begin(dev, [agg_k, agg_bk, _lib.K_GEMM, _lib.K_GEMM_WGRAD])
     for _ in range(args.steps):
         eager_step()
     torch.cuda.synchronize()
+    ops.set_wgrad_side_stream(not args.no_side_stream)
     n_f, ms_f = ops.prof_read(dev, agg_k)
     n_b, ms_b = ops.prof_read(dev, agg_bk)
     n_g, ms_g = ops.prof_read(dev, _lib.K_GEMM)
@@ -219,6 +223,10 @@ def main():
                          "bwd": {"alg_bytes_per_launch": alg_b, "avg_us": ms_b / max(n_b, 1) * 1e3,
                                  "achieved": (alg_b / (ms_b / max(n_b, 1) * 1e-3) / 1e9) if n_b else 0.0}},
             "mfma": {"ref_flops_per_graph_fwd_bwd": flops, "peak_tflops": MFMA_F32_PEAK_TF,
+                     "arithmetic": "fp32 operands as three bf16 pieces, six bf16 MFMAs per product, fp32 accumulation "
+                                   "(GNX_GEMM_SPLIT=0 selects the exact-fp32 MFMA kernels); weight gradients: fp32 MFMA",
+                     # reference-formulation FLOPs delivered per second, as a fraction of the fp32-MFMA peak: the
+                     # restructured layers do fewer FLOPs than the reference formulation, so this is a speed ratio
                      "model_frac_of_f32_mfma_peak": (flops * value / world / 1e12 / MFMA_F32_PEAK_TF) if flops else None,
                      "gemm_ms_per_step": ms_g / args.steps, "gemm_launches_per_step": n_g / args.steps,
                      "wgrad_ms_per_step": ms_w / args.steps, "wgrad_launches_per_step": n_w / args.steps},

@@ -1253,7 +1253,8 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   bool any_rs = false;
   for (int q = 0; q < nseg; ++q) any_rs = any_rs || g.seg[q].rs != nullptr;
   // row-scaled segments (the 4-segment post-layer-0 of hub-heavy batches) stay on the fp32-MFMA kernel
-  const bool split = vec && ksteps >= 2 && !any_rs && !(split_env && atoi(split_env) == 0);
+  // small problems are launch-bound: the extra weight-split launch costs more than the faster matrix-core path saves
+  const bool split = vec && ksteps >= 2 && !any_rs && M >= 4096 && !(split_env && atoi(split_env) == 0);
   if (split) {
     split_args sa;
     for (int q = 0; q < MAX_SEGS; ++q) sa.seg[q] = g.seg[q];

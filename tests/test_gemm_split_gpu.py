@@ -1,0 +1,125 @@
+"""GPU parity of the tiled split-operand GEMM (k_split_weights + k_gemm3: multi-segment / grouped / wide products with
+M >= 4096) against fp64 torch: both weight layouts, ragged M / K / N, several column tiles, persistent tile walk over
+more tiles than workgroups, degree-class grouping, all epilogues, strided views; and against the exact-fp32 MFMA
+kernel (GNX_GEMM_SPLIT=0)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.parity_util import rel_err
+from tests.test_ops_gpu import _graph, _pack
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("M", [4096, 20037, 70000])
+def test_two_segments_nt_bias_relu(gpu_device, M):
+    """post-layer-0 shape: [x | A] (K = 128 + 512) against W[:, :640], bias + ReLU."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(M)
+    F = 128
+    x, A = torch.randn(M, F), torch.randn(M, 4 * F)
+    W, b = torch.randn(F, 13 * F) / 8, torch.randn(F)
+    ref = (torch.cat([x, A], 1).double() @ W[:, :5 * F].double().T + b.double()).relu()
+    out = torch.full((M, F), float("nan"), device=gpu_device)
+    Wd = W.to(gpu_device)
+    ops.gemm([(x.to(gpu_device), None, Wd[:, :F]), (A.to(gpu_device), None, Wd[:, F:5 * F])], out,
+             bias=b.to(gpu_device), relu=True)
+    assert rel_err(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(8200, 512, 128), (4100, 132, 100), (33000, 256, 256)])
+def test_nn_wide_mask_and_accumulate(gpu_device, M, N, K):
+    """dA shape (several column tiles share the A rows), NN weights, ReLU-mask and accumulate epilogues."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(M + N)
+    a, w = torch.randn(M, K), torch.randn(K, N) / 4
+    mask, c0 = torch.randn(M, N), torch.randn(M, N)
+    ad, wd = a.to(gpu_device), w.to(gpu_device)
+    prod = a.double() @ w.double()
+    out = torch.full((M, N), float("nan"), device=gpu_device)
+    ops.gemm([(ad, None, wd)], out, b_trans=False)
+    assert rel_err(out, prod) <= TOL
+    out = torch.full((M, N), float("nan"), device=gpu_device)
+    ops.gemm([(ad, None, wd)], out, b_trans=False, mask=mask.to(gpu_device))
+    assert rel_err(out, prod * (mask > 0)) <= TOL
+    out = c0.clone().to(gpu_device)
+    ops.gemm([(ad, None, wd)], out, b_trans=False, accumulate=True)
+    assert rel_err(out, c0.double() + prod) <= TOL
+
+
+def test_three_segments_nn_ragged_k_strided_views(gpu_device):
+    """dx shape: three products accumulated in one launch; k not a multiple of 32, operands and output are column
+    slices of wider tensors; nothing is written outside the output view."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(4)
+    M, H = 9001, 384
+    G3 = torch.randn(M, H)
+    W = torch.randn(3, 128, 132) / 4
+    gd, wd = G3.to(gpu_device), W.to(gpu_device)
+    ks = (100, 36, 128)
+    segs, ref = [], 0
+    for i, k in enumerate(ks):
+        segs.append((gd[:, 128 * i:128 * i + k], None, wd[i, :k, :]))
+        ref = ref + G3[:, 128 * i:128 * i + k].double() @ W[i, :k, :].double()
+    out = torch.zeros(M, 512, device=gpu_device)
+    ops.gemm(segs, out[:, 128:260], b_trans=False)
+    assert rel_err(out[:, 128:260], ref) <= TOL
+    assert float(out[:, :128].abs().max()) == 0.0 and float(out[:, 260:].abs().max()) == 0.0
+
+
+def test_grouped_by_degree_class(gpu_device):
+    """x W0^T + A Weff(d)^T with rows gathered per in-degree class (tiles never straddle classes; more tiles than
+    workgroups so the persistent walk wraps) and the matching input gradient."""
+    from gnnepcsaft_amd import ops
+    rng = np.random.default_rng(33)
+    N, E, F = 90000, 200000, 64
+    ei = _graph(rng, N, E)
+    g = _pack(ei, None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    assert dc is not None
+    avg = 1.2
+    amp, att = g.degree_scalers(avg)
+    torch.manual_seed(6)
+    x, A = torch.randn(N, F), torch.randn(N, 4 * F)
+    W, b = torch.randn(F, 13 * F) / 8, torch.randn(F)
+    xd, Ad, Wd, bd = x.to(gpu_device), A.to(gpu_device), W.to(gpu_device), b.to(gpu_device)
+    cat = torch.cat([x, A, A * amp.cpu()[:, None], A * att.cpu()[:, None]], 1).double()
+    ref = (cat @ W.double().T + b.double()).relu()
+    weff = ops.pna_weff(Wd, F, dc.D, avg)
+    z = torch.full((N, F), float("nan"), device=gpu_device)
+    ops.gemm_grouped([(xd, None, Wd[:, 0:F], 0), (Ad, None, weff[0], 4 * F * F)], z, dc, bias=bd, relu=True)
+    assert rel_err(z, ref) <= TOL
+    gr = torch.randn(N, F)
+    ref_dA = gr.double() @ W[:, F:5 * F].double() + (gr * amp.cpu()[:, None]).double() @ W[:, 5 * F:9 * F].double() + \
+        (gr * att.cpu()[:, None]).double() @ W[:, 9 * F:].double()
+    dA = torch.full((N, 4 * F), float("nan"), device=gpu_device)
+    ops.gemm_grouped([(gr.to(gpu_device), None, weff[0], 4 * F * F)], dA, dc, b_trans=False)
+    assert rel_err(dA, ref_dA) <= TOL
+
+
+def test_split_and_exact_kernels_agree(gpu_device):
+    """Same call through the split-operand kernel and the exact-fp32 MFMA kernel: both within 1e-5 of fp64 and within
+    2e-6 (norm-wise) of each other."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(9)
+    M, F = 12345, 128
+    x, A = torch.randn(M, F), torch.randn(M, 4 * F)
+    W = torch.randn(F, 5 * F) / 8
+    xd, Ad, Wd = x.to(gpu_device), A.to(gpu_device), W.to(gpu_device)
+    ref = torch.cat([x, A], 1).double() @ W.double().T
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["GNX_GEMM_SPLIT"] = mode
+        try:
+            out = torch.empty(M, F, device=gpu_device)
+            ops.gemm([(xd, None, Wd[:, :F]), (Ad, None, Wd[:, F:])], out)
+            outs[mode] = out.double().cpu()
+        finally:
+            os.environ.pop("GNX_GEMM_SPLIT", None)
+    assert rel_err(outs["1"], ref) <= TOL and rel_err(outs["0"], ref) <= TOL
+    assert rel_err(outs["1"], outs["0"]) <= 2e-6
+    assert rel_err(outs["1"], ref) <= rel_err(outs["0"], ref) * 1.5 + 1e-8
