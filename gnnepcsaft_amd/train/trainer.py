@@ -38,6 +38,53 @@ class DataLoader:
             yield Batch.from_data_list([self.dataset[j] for j in order[i:i + self.batch_size]])
 
 
+# Classes a Lightning ``.ckpt`` of the reference pickles next to its ``state_dict``: ``save_hyperparameters(config)``
+# (/root/reference/gnnepcsaft/train/models.py:31) stores an ``ml_collections.ConfigDict``.  ml_collections is not
+# installed here, and nothing from a checkpoint may be executed: the safe loader is given inert stand-ins under those
+# import paths, which only keep the pickled state.
+_INERT_CLASSES = (
+    ("ml_collections.config_dict.config_dict", "ConfigDict"),
+    ("ml_collections.config_dict.config_dict", "FrozenConfigDict"),
+    ("ml_collections.config_dict.config_dict", "FieldReference"),
+)
+
+
+class _Inert:
+    """Holds whatever state the pickle carries; runs no code from the file."""
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+
+    def plain(self):
+        return _plain(self.__dict__.get("_state", self.__dict__))
+
+
+def _plain(obj):
+    """Recursively turns inert stand-ins / containers into plain dicts and lists (ConfigDict keeps its entries under
+    ``_fields``; a FieldReference its value under ``_value``)."""
+    if isinstance(obj, _Inert):
+        return obj.plain()
+    if isinstance(obj, dict):
+        if "_fields" in obj and isinstance(obj["_fields"], dict):
+            return _plain(obj["_fields"])
+        if "_value" in obj and len(obj) <= 4:
+            return _plain(obj["_value"])
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    return obj
+
+
+def read_checkpoint(path: str) -> dict:
+    """Reads this trainer's checkpoints and Lightning ``.ckpt`` files (train.py:121-151 of the reference) with
+    ``torch.load(weights_only=True)``; hyper-parameter containers of classes that are not importable come back as
+    plain dicts.  Returns the checkpoint dict (``state_dict``, ``global_step``, ``hyper_parameters`` …)."""
+    stubs = [type(name, (_Inert,), {"__module__": module}) for module, name in _INERT_CLASSES]
+    with torch.serialization.safe_globals(stubs):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    return {k: (_plain(v) if k != "state_dict" else v) for k, v in ckpt.items()}
+
+
 class Trainer:
     def __init__(self, max_steps: int = -1, log_every_n_steps: int = 50, val_check_interval: Optional[int] = None,
                  default_root_dir: Optional[str] = None, enable_checkpointing: bool = True, fused_optimizer: bool = True,
@@ -61,9 +108,9 @@ class Trainer:
 
     @staticmethod
     def load_state_dict(model, path: str) -> dict:
-        """Reads a checkpoint's ``state_dict`` (this trainer's, or a Lightning ``.ckpt`` whose payload the safe loader
-        accepts) with ``weights_only=True`` — nothing from the file is executed."""
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        """Reads a checkpoint's ``state_dict`` (this trainer's, or a Lightning ``.ckpt``) with ``weights_only=True`` —
+        nothing from the file is executed (``read_checkpoint``)."""
+        ckpt = read_checkpoint(path)
         model.load_state_dict(ckpt["state_dict"])
         return ckpt
 

@@ -214,3 +214,41 @@ def test_oracle_reproduces_golden(name):
     got32 = run_case(CASES[name], dtype=torch.float32)  # the reference's working precision, loose (conditioning)
     assert abs(float(got32["loss"]) - float(gold["loss"])) <= 1e-5 * abs(float(gold["loss"]))
     assert float(np.abs(got32["pred"] - gold["pred"]).max()) <= 2e-3 * float(np.abs(gold["pred"]).max())
+
+
+def test_lightning_style_checkpoint_with_configdict_is_read_without_executing_it(tmp_path):
+    """a Lightning ``.ckpt`` carries ``hyper_parameters`` as an ``ml_collections.ConfigDict`` (not
+    installed).  A file pickled against a throw-away module of that import path must load through the safe loader once
+    the module is gone again, with the hyper-parameters back as plain dicts and the tensors intact."""
+    import sys
+    import types
+    from gnnepcsaft_amd.train.trainer import read_checkpoint
+
+    names = ["ml_collections", "ml_collections.config_dict", "ml_collections.config_dict.config_dict"]
+    assert not any(n in sys.modules for n in names), "ml_collections unexpectedly importable: adapt this test"
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class ConfigDict:  # default object pickling (NEWOBJ + BUILD), entries under _fields like the real class
+        def __init__(self, d):
+            self._fields = {k: (ConfigDict(v) if isinstance(v, dict) else v) for k, v in d.items()}
+            self._locked, self._type_safe = False, True
+
+    ConfigDict.__module__ = names[2]
+    ConfigDict.__qualname__ = "ConfigDict"
+    mods[names[2]].ConfigDict = ConfigDict
+    sys.modules.update(mods)
+    try:
+        sd = {"model.mlp.6.weight": torch.arange(12.0).reshape(3, 4), "model.mlp.6.bias": torch.ones(3)}
+        cfg = {"conv": "PNA", "hidden_dim": 128, "nested": {"lr": 1e-3, "deg": [1, 2, 3]}}
+        path = tmp_path / "last.ckpt"
+        torch.save({"state_dict": sd, "global_step": 7, "epoch": 2, "pytorch-lightning_version": "2.5.0",
+                    "hyper_parameters": {"config": ConfigDict(cfg)}, "hparams_name": "kwargs"}, path)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    with pytest.raises(Exception):  # the plain safe loader refuses the unknown class
+        torch.load(path, map_location="cpu", weights_only=True)
+    ckpt = read_checkpoint(str(path))
+    assert ckpt["global_step"] == 7 and ckpt["hyper_parameters"]["config"] == cfg
+    assert torch.equal(ckpt["state_dict"]["model.mlp.6.weight"], sd["model.mlp.6.weight"])
+    assert not any(n in sys.modules for n in names)
