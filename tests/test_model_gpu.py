@@ -97,6 +97,21 @@ def test_model_cfg2_shape_vs_fp64(gpu_device):
     assert_as_close_as_cpu_fp32(res)
 
 
+@pytest.mark.parametrize("conv,hidden,graphs", [("PNA", 128, 640), ("GINE", 256, 512)])
+def test_model_at_large_batch_kernels(gpu_device, conv, hidden, graphs):
+    """Batches of >= 8192 atoms select the large-batch kernels (split-operand products, degree classes, one-hot MFMA
+    embedding gradient, recomputing scatter backward) that the 32-graph cases never reach: same three-way criterion
+    against the fp64 oracle, two layers to keep the CPU oracle at a few seconds."""
+    from gnnepcsaft_amd.data import synthetic_batch
+    cfg = _cfg(conv=conv, hidden_dim=hidden, propagation_depth=2)
+    res = compare_with_oracle(cfg, synthetic_batch(graphs, 2 if conv == "PNA" else 3), device="cuda:0")
+    print("large", conv, res)
+    assert res["loss_rel"] <= 1e-5, res
+    assert_as_close_as_cpu_fp32(res)
+    if conv == "GINE":
+        assert res["pred_rel"] <= 1e-5, res
+
+
 @pytest.mark.parametrize("name", ["pna_h32_l2_t2", "gine_h32_l2"])
 def test_hip_path_against_committed_golden_vectors(gpu_device, name):
     """HIP forward/backward vs the committed fp64 golden vectors (tests/golden/*.npz; generating script alongside).
