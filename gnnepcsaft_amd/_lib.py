@@ -127,6 +127,14 @@ def check(status: int) -> None:
         raise GnxError(status, last_error())
 
 
+_bound_stream: dict = {}
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream  # pylint: disable=protected-access
+except AttributeError:  # pragma: no cover - older torch
+    def _raw_stream(idx: int) -> int:
+        return torch.cuda.current_stream(idx).cuda_stream
+
+
 def handle(device: torch.device) -> int:
     """Opaque gnx_handle* for a CUDA(HIP) device, bound to torch's current stream on that device."""
     if device.type != "cuda":
@@ -140,5 +148,10 @@ def handle(device: torch.device) -> int:
         check(lib.gnx_create(C.byref(out), idx))
         h = out.value
         _handles[idx] = h
-    check(lib.gnx_set_stream(h, torch.cuda.current_stream(idx).cuda_stream))
+    # raw stream pointer without building a torch.cuda.Stream object (this runs once per launch); the library call is
+    # skipped while the stream has not changed
+    stream = _raw_stream(idx)
+    if _bound_stream.get(idx) != stream:
+        check(lib.gnx_set_stream(h, stream))
+        _bound_stream[idx] = stream
     return h

@@ -92,3 +92,16 @@ int32_t gnx_read_flag(gnx_handle* h, int* value);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Zero-fill as a kernel launch: hipMemsetAsync costs ~50 us of host time per call on this stack (it showed up as idle
+// gaps of that size between the packer's tiny kernels); a launch costs ~5 us.
+template <typename T>
+__global__ void k_zero_fill(T* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = T(0);
+}
+static inline void gnx_zero_ints(gnx_handle* h, int* p, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_zero_fill<int>, dim3((unsigned)gnx_cdiv(n, 256)), dim3(256), 0, h->stream, p, n);
+}
+

@@ -142,14 +142,14 @@ __global__ void k_gather_endpoints(const int* __restrict__ perm, const int* __re
 
 static int32_t group_by_key(gnx_handle* h, const int* key, int64_t E, int64_t N, int* ptr, int* items, int* cursor,
                             int* scan_ws) {
-  GNX_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(N > 0 ? N : 1), h->stream));
+  gnx_zero_ints(h, cursor, N > 0 ? N : 1);
   if (E > 0) {
     hipLaunchKernelGGL(k_count_keys, dim3((unsigned)gnx_cdiv(E, 256)), dim3(256), 0, h->stream, key, E, cursor);
     GNX_LAUNCH_CHECK();
   }
   int32_t st = exclusive_scan(h, cursor, ptr, N, scan_ws, true);
   if (st != GNX_OK) return st;
-  GNX_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(N > 0 ? N : 1), h->stream));
+  gnx_zero_ints(h, cursor, N > 0 ? N : 1);
   if (E > 0) {
     hipLaunchKernelGGL(k_fill_groups, dim3((unsigned)gnx_cdiv(E, 256)), dim3(256), 0, h->stream, key, E, ptr, cursor,
                        items);
@@ -312,7 +312,7 @@ __global__ void k_degree_max(const int* __restrict__ rowptr, int64_t N, int* __r
 extern "C" int32_t gnx_degree_max(gnx_handle* h, const int32_t* rowptr, int64_t N, int32_t* max_degree_host) {
   GNX_CHECK_ARG(h && max_degree_host && N >= 0 && (N == 0 || rowptr), "gnx_degree_max: bad argument");
   int* d_out = h->d_flag + 8;  // scratch word inside the handle's flag block
-  GNX_HIP(hipMemsetAsync(d_out, 0, sizeof(int), h->stream));
+  gnx_zero_ints(h, d_out, 1);
   if (N > 0) {
     hipLaunchKernelGGL(k_degree_max, dim3((unsigned)gnx_cdiv(N, 256)), dim3(256), 0, h->stream, rowptr, N, d_out);
     GNX_LAUNCH_CHECK();

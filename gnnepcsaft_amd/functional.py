@@ -51,7 +51,7 @@ def _empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
 
 
 def _zeros_like(t: torch.Tensor) -> torch.Tensor:
-    return torch.zeros(t.shape, dtype=torch.float32, device=t.device)
+    return ops.zeros(*t.shape, device=t.device)
 
 
 class EmbedSumFn(torch.autograd.Function):
@@ -90,7 +90,7 @@ class LinearFn(torch.autograd.Function):
         dw = sw if sw is not None else _zeros_like(weight)
         db = None
         if ctx.has_bias:
-            db = sb if sb is not None else torch.zeros(weight.size(0), dtype=torch.float32, device=dy.device)
+            db = sb if sb is not None else ops.zeros(weight.size(0), device=dy.device)
         ops.gemm_wgrad(dy, x, dw, dbias=db)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -341,11 +341,11 @@ class GINEConvFn(torch.autograd.Function):
         dev = dict(dtype=torch.float32, device=x.device)
         sk = ctx.sinks
         dlw = sk[0] if sk[0] is not None else _zeros_like(lin_w)
-        dlb = sk[1] if sk[1] is not None else torch.zeros(lin_w.size(0), **dev)
+        dlb = sk[1] if sk[1] is not None else ops.zeros(lin_w.size(0), device=x.device)
         dw0 = sk[2] if sk[2] is not None else _zeros_like(w0)
-        db0 = sk[3] if sk[3] is not None else torch.zeros(w0.size(0), **dev)
+        db0 = sk[3] if sk[3] is not None else ops.zeros(w0.size(0), device=x.device)
         dw2 = sk[4] if sk[4] is not None else _zeros_like(w2)
-        db2 = sk[5] if sk[5] is not None else torch.zeros(w2.size(0), **dev)
+        db2 = sk[5] if sk[5] is not None else ops.zeros(w2.size(0), device=x.device)
         ops.gemm_wgrad(dout, a1, dw2, dbias=db2)
         g1 = ops.gemm([(dout, None, w2)], _empty(N, a1.size(1), x), b_trans=False, mask=a1)
         ops.gemm_wgrad(g1, agg, dw0, dbias=db0)

@@ -6,6 +6,7 @@ require HIP-device fp32 / int64 / int32 tensors and raise ``GnxError`` otherwise
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -24,12 +25,14 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def _mat(t: torch.Tensor, name: str) -> Tuple[int, int]:
     """(data_ptr, leading dimension) of a 2-D fp32 view whose rows are contiguous."""
-    _f32(t, name)
-    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+    if t.dtype is not torch.float32:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"{name}: expected float32, got {t.dtype}")
+    shape, strides = t.shape, t.stride()
+    if len(shape) != 2 or (shape[1] > 1 and strides[1] != 1):
         raise _lib.GnxError(_lib.GNX_E_INVALID, f"{name}: need a 2-D view with unit column stride, got "
-                                                f"shape {tuple(t.shape)} strides {t.stride()}")
-    ld = t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
-    return t.data_ptr(), max(ld, t.size(1))
+                                                f"shape {tuple(shape)} strides {strides}")
+    ld = strides[0]
+    return t.data_ptr(), (ld if ld > shape[1] else shape[1])
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -38,6 +41,21 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _carr(vals: Sequence[int]):
     return (_I32 * len(vals))(*vals)
+
+
+def zeros(*shape: int, device: torch.device) -> torch.Tensor:
+    """fp32 zeros through a fill launch: ``torch.zeros`` / ``zero_()`` go through hipMemsetAsync, which costs ~50 us of
+    host time per call here (the launch path is on the critical path of the step)."""
+    t = torch.empty(*shape, dtype=torch.float32, device=device)
+    return zero_(t)
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
+        if t.numel():
+            check(_lib.load().gnx_fill(handle(t.device), t.data_ptr(), t.numel(), 0.0))
+        return t
+    return t.zero_()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -212,7 +230,7 @@ def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor)
     dout = _f32(dout, "dout").contiguous()
     idx = idx.contiguous()
     H = dout.size(1)
-    dtable = torch.zeros(R, H, dtype=torch.float32, device=dout.device)
+    dtable = zeros(R, H, device=dout.device)
     lib = _lib.load()
     nbytes = lib.gnx_table_scatter_workspace_bytes(idx.size(0), R, H)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dout.device)
@@ -227,6 +245,16 @@ def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor)
 Seg = Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]  # (A view [M,k], rowscale [M] | None, B view)
 
 
+class _SegArrays(threading.local):
+    """Per-thread reusable descriptor arrays (forward runs on the caller's thread, backward on autograd's)."""
+
+    def __init__(self):
+        self.by_len = {n: (GemmSeg * n)() for n in range(1, 5)}
+
+
+_SEG_ARRAYS = _SegArrays()
+
+
 def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          mask: Optional[torch.Tensor] = None, relu: bool = False, accumulate: bool = False,
          b_trans: bool = True) -> torch.Tensor:
@@ -238,17 +266,17 @@ def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor]
     if M == 0:
         return out
     cptr, ldc = _mat(out, "out")
-    arr = (GemmSeg * len(segs))()
+    arr = _SEG_ARRAYS.by_len[len(segs)]  # reused: the library copies the descriptors during the call
     for i, (a, rs, b) in enumerate(segs):
-        ap, lda = _mat(a, f"A[{i}]")
-        bp, ldb = _mat(b, f"B[{i}]")
-        k = a.size(1)
-        if a.size(0) != M or (b_trans and (b.size(0) != N or b.size(1) != k)) or \
-                (not b_trans and (b.size(0) != k or b.size(1) != N)):
+        ap, lda = _mat(a, "A")
+        bp, ldb = _mat(b, "B")
+        (am, k), (b0, b1) = a.shape, b.shape
+        if am != M or (b_trans and (b0 != N or b1 != k)) or (not b_trans and (b0 != k or b1 != N)):
             raise _lib.GnxError(_lib.GNX_E_INVALID, f"gemm segment {i}: A {tuple(a.shape)} B {tuple(b.shape)} "
                                                     f"out {tuple(out.shape)} b_trans={b_trans}")
-        arr[i].a, arr[i].lda, arr[i].rowscale = ap, lda, _ptr(rs)
-        arr[i].b, arr[i].ldb, arr[i].k = bp, ldb, k
+        e = arr[i]
+        e.a, e.lda, e.rowscale = ap, lda, (None if rs is None else rs.data_ptr())
+        e.b, e.ldb, e.k = bp, ldb, k
     flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0) | \
             (_lib.GEMM_B_TRANS if b_trans else 0)
     mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
@@ -448,7 +476,7 @@ def pna_post0_wgrad_classes(g: torch.Tensor, A: torch.Tensor, dc: "DegreeClasses
     """dW[:, F:13F] += the three A-blocks of post-layer 0's weight gradient, through per-degree-class partial sums."""
     if g.size(0) == 0:
         return
-    dWeff = torch.zeros(dc.D, F, 4 * F, dtype=torch.float32, device=g.device)
+    dWeff = zeros(dc.D, F, 4 * F, device=g.device)
 
     def run():
         gemm_wgrad_grouped(g, A, dWeff, dc)
@@ -486,7 +514,7 @@ def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tens
     H = gr.size(1)
     dP = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
     dQ = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
-    dTe = torch.zeros(R, H, dtype=torch.float32, device=gr.device)
+    dTe = zeros(R, H, device=gr.device)
     lib = _lib.load()
     pos = g.code_index(R) if (H % 4 == 0 and H <= 1024) or H <= 256 else None
     if pos is not None:
@@ -530,7 +558,7 @@ def gine_aggregate_fwd(x: torch.Tensor, Le: torch.Tensor, g: GraphPack, eps: flo
 def gine_aggregate_bwd(dout: torch.Tensor, x: torch.Tensor, Le: torch.Tensor, g: GraphPack,
                        eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     dx = torch.empty_like(x)
-    dLe = torch.zeros_like(Le)
+    dLe = zeros(*Le.shape, device=Le.device)
     check(_lib.load().gnx_gine_aggregate_bwd(handle(x.device), dout.data_ptr(), x.data_ptr(), Le.data_ptr(),
                                              g.colptr.data_ptr(), g.cpos.data_ptr(), g.src.data_ptr(),
                                              g.dst.data_ptr(), g.code.data_ptr(), g.N, g.E, x.size(1), Le.size(0),
@@ -582,9 +610,9 @@ def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu: bool, dgamma=None, dbeta=No
     M, H = x.shape
     dx = torch.empty_like(x)
     if dgamma is None:
-        dgamma = torch.zeros(H, dtype=torch.float32, device=x.device)
+        dgamma = zeros(H, device=x.device)
     if dbeta is None:
-        dbeta = torch.zeros(H, dtype=torch.float32, device=x.device)
+        dbeta = zeros(H, device=x.device)
     ws, nbytes = _bn_ws(M, H, x.device)
     check(_lib.load().gnx_batchnorm_bwd(handle(x.device), dy.data_ptr(), x.data_ptr(), y.data_ptr(), M, H, _ptr(gamma),
                                         mean.data_ptr(), rstd.data_ptr(), int(relu), dx.data_ptr(), dgamma.data_ptr(),
