@@ -45,13 +45,52 @@ extern "C" int32_t gnx_destroy(gnx_handle* h) {
   (void)hipFree(h->d_flag);
   (void)hipFree(h->d_scratch);
   for (auto& w : h->wsplit) (void)hipFree(w.buf);
+  if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+  if (h->side_done) (void)hipEventDestroy(h->side_done);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return GNX_OK;
 }
 
 extern "C" int32_t gnx_set_stream(gnx_handle* h, void* hip_stream) {
   GNX_CHECK_ARG(h != nullptr, "gnx_set_stream: handle is NULL");
+  GNX_CHECK_ARG(!h->on_side, "gnx_set_stream: between gnx_side_begin and gnx_side_end");
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_side_begin(gnx_handle* h) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_side_begin: handle is NULL");
+  GNX_CHECK_ARG(!h->on_side, "gnx_side_begin: already on the side stream");
+  if (h->side == nullptr) {
+    GNX_HIP(hipSetDevice(h->device));
+    GNX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+  }
+  GNX_HIP(hipEventRecord(h->side_fork, h->stream));
+  GNX_HIP(hipStreamWaitEvent(h->side, h->side_fork, 0));
+  h->main_saved = h->stream;
+  h->stream = h->side;
+  h->on_side = true;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_side_end(gnx_handle* h) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_side_end: handle is NULL");
+  if (h->on_side) {
+    h->stream = h->main_saved;
+    h->on_side = false;
+  }
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_side_join(gnx_handle* h) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_side_join: handle is NULL");
+  GNX_CHECK_ARG(!h->on_side, "gnx_side_join: between gnx_side_begin and gnx_side_end");
+  if (h->side == nullptr) return GNX_OK;
+  GNX_HIP(hipEventRecord(h->side_done, h->side));
+  GNX_HIP(hipStreamWaitEvent(h->stream, h->side_done, 0));
   return GNX_OK;
 }
 

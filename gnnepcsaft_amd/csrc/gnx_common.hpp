@@ -16,6 +16,11 @@ struct gnx_handle {
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;
   float* d_scratch = nullptr;  // 4 KiB
+  // side stream (gnx_side_begin/end/join): created on first use; `stream` is swapped to it between begin and end
+  hipStream_t side = nullptr;
+  hipStream_t main_saved = nullptr;
+  hipEvent_t side_fork = nullptr, side_done = nullptr;
+  bool on_side = false;
   // split-weight images of the tiled GEMM (k_split_weights -> k_gemm3): one growable buffer per stream that used it
   struct wsplit_buf {
     hipStream_t stream;

@@ -339,9 +339,9 @@ def pna_weff_bwd(dWeff: torch.Tensor, F: int, D: int, avg_deg_log: float, dW: to
     check(_lib.load().gnx_pna_weff_bwd(handle(dW.device), dWeff.data_ptr(), F, D, float(avg_deg_log), wp, ldw))
 
 
-_SIDE_STREAMS = {}
 _SIDE_ENABLED = False
-_SIDE_PENDING = set()
+_SIDE_PENDING = set()   # device indices with weight-gradient launches not yet joined
+_SIDE_KEEP: dict = {}   # device index -> buffers those launches touch, kept alive until the join
 
 
 def set_wgrad_side_stream(enabled: bool) -> None:
@@ -354,12 +354,18 @@ def set_wgrad_side_stream(enabled: bool) -> None:
 _JOIN_QUEUED = False
 
 
+def _join(idx: int) -> None:
+    dev = torch.device("cuda", idx)
+    check(_lib.load().gnx_side_join(handle(dev)))
+    _SIDE_PENDING.discard(idx)
+    _SIDE_KEEP.pop(idx, None)  # later users of these blocks are ordered behind the join on the main stream
+
+
 def _join_all_side_streams() -> None:
     global _JOIN_QUEUED
     _JOIN_QUEUED = False
     for idx in list(_SIDE_PENDING):
-        torch.cuda.current_stream(idx).wait_stream(_SIDE_STREAMS[idx])
-        _SIDE_PENDING.discard(idx)
+        _join(idx)
 
 
 def join_side_stream_at_end_of_backward() -> None:
@@ -438,28 +444,25 @@ def join_side_stream(device: torch.device) -> None:
     """Make the current stream wait for all weight-gradient kernels issued on the side stream."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx in _SIDE_PENDING:
-        torch.cuda.current_stream(idx).wait_stream(_SIDE_STREAMS[idx])
-        _SIDE_PENDING.discard(idx)
+        _join(idx)
 
 
 def _run_on_side(ref: torch.Tensor, tensors, fn) -> None:
-    """Run ``fn`` (weight-gradient launches) on the side stream when enabled, else inline.  ``tensors`` are the device
-    buffers the launches read or write that could be freed before the side stream has run."""
+    """Run ``fn`` (weight-gradient launches) on the library's side stream when enabled, else inline.  ``tensors`` are
+    the device buffers the launches read or write; they are kept referenced until the join so the caching allocator
+    cannot hand them out again under the side kernels (fork / join are two HIP event calls inside the library:
+    gnx_side_begin / gnx_side_join)."""
     if _SIDE_ENABLED and ref.is_cuda:
         idx = ref.device.index
-        side = _SIDE_STREAMS.get(idx)
-        if side is None:
-            side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-        main = torch.cuda.current_stream(idx)
-        if main != side:
-            side.wait_stream(main)  # operands were produced on the main stream
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(side)  # keep the allocator from recycling them under the side kernels
-            _SIDE_PENDING.add(idx)
-            with torch.cuda.stream(side):
-                fn()
-            return
+        lib, h = _lib.load(), handle(ref.device)
+        check(lib.gnx_side_begin(h))
+        try:
+            fn()
+        finally:
+            check(lib.gnx_side_end(h))
+        _SIDE_KEEP.setdefault(idx, []).extend(t for t in tensors if t is not None)
+        _SIDE_PENDING.add(idx)
+        return
     fn()
 
 

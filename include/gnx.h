@@ -267,6 +267,15 @@ int32_t gnx_sgd(gnx_handle* h, float* p, const float* g, int64_t n, float lr);
 
 /* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
 int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
+
+/* Second stream for work that is independent of the caller's stream (the weight gradients of a layer's backward;
+ * stands in for what the reference gets from autograd's per-op CUDA streams under DDP, ref: train/train.py:85-88).
+ * gnx_side_begin: the handle's own side stream waits for everything queued so far on the bound stream, and every
+ *   launch until gnx_side_end goes to the side stream.  gnx_side_join: the bound stream waits for the side stream.
+ * Buffers touched by side-stream launches must stay allocated until the join (the caller keeps them alive). */
+int32_t gnx_side_begin(gnx_handle* h);
+int32_t gnx_side_end(gnx_handle* h);
+int32_t gnx_side_join(gnx_handle* h);
 /* y[m,:] = clip(x[m,:], lo[:], hi[:])   (pred_with_bounds, ref: train/models.py:246-253) */
 int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo, const float* hi, float* y);
 
