@@ -81,8 +81,8 @@ SIGNATURES = {
     "gnx_segment_pool_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_segment_pool_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_batchnorm_workspace_bytes": (_sz, [_i64, _i32]),
-    "gnx_batchnorm_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                 _sz]),
+    "gnx_batchnorm_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _vp, _vp, _vp,
+                                 _vp, _sz]),
     "gnx_batchnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz]),
     "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gnx_adamw_amsgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),

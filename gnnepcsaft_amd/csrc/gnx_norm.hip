@@ -183,8 +183,9 @@ __global__ void k_bn_finalize(const float* __restrict__ x, const float* __restri
                               int H, const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                               float eps, int training, float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                              float* __restrict__ ab) {
+                              float* __restrict__ ab, int64_t* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (training && num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
   float t1 = 0.f, t2 = 0.f;
   if (training) bn_fold(part, chunks, H, c, t1, t2);
   if (c >= H || (threadIdx.x >> 4) != 0) return;
@@ -238,9 +239,10 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float* __restrict__ x, i
 }
 
 extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, int32_t H, const float* gamma,
-                                     const float* beta, float* running_mean, float* running_var, float momentum,
-                                     float eps, int32_t training, int32_t relu, float* y, float* save_mean,
-                                     float* save_rstd, void* ws, size_t ws_bytes) {
+                                     const float* beta, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, float momentum, float eps, int32_t training,
+                                     int32_t relu, float* y, float* save_mean, float* save_rstd, void* ws,
+                                     size_t ws_bytes) {
   GNX_CHECK_ARG(h && H > 0 && M >= 0, "gnx_batchnorm_fwd: bad argument");
   if (M == 0) return GNX_OK;
   GNX_CHECK_ARG(x && y && ws, "gnx_batchnorm_fwd: NULL argument");
@@ -263,7 +265,8 @@ extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, i
     GNX_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)gnx_cdiv(H, 16)), dim3(256), 0, h->stream, x, part, chunks, M, (int)H,
-                     gamma, beta, running_mean, running_var, momentum, eps, (int)training, save_mean, save_rstd, ab);
+                     gamma, beta, running_mean, running_var, momentum, eps, (int)training, save_mean, save_rstd, ab,
+                     num_batches_tracked);
   GNX_LAUNCH_CHECK();
   int64_t total = M * H;
   if (H % 4 == 0) {

@@ -54,19 +54,52 @@ def _zeros_like(t: torch.Tensor) -> torch.Tensor:
     return ops.zeros(*t.shape, device=t.device)
 
 
+def adjacent_rows(tensors: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """If the 2-D fp32 tensors are consecutive row blocks of one allocation (same width, contiguous, back to back),
+    returns a [sum rows, H] view over all of them (no copy), else None."""
+    t0 = tensors[0]
+    if t0.dim() != 2 or t0.dtype is not torch.float32 or not t0.is_contiguous():
+        return None
+    H = t0.size(1)
+    ptr, rows = t0.data_ptr(), 0
+    for t in tensors:
+        if t.dim() != 2 or t.size(1) != H or t.dtype is not torch.float32 or not t.is_contiguous() or \
+                t.device != t0.device or t.data_ptr() != ptr + rows * H * 4:
+            return None
+        rows += t.size(0)
+    if t0.untyped_storage().nbytes() - t0.storage_offset() * 4 < rows * H * 4:
+        return None
+    return torch.as_strided(t0.detach(), (rows, H), (H, 1))
+
+
 class EmbedSumFn(torch.autograd.Function):
-    """[3P] ogb AtomEncoder/BondEncoder.forward: sum_k Embedding_k(idx[:,k]) (models.py:205-206)."""
+    """[3P] ogb AtomEncoder/BondEncoder.forward: sum_k Embedding_k(idx[:,k]) (models.py:205-206).
+
+    ``weights`` are the K embedding tables.  When they are consecutive row blocks of one buffer (the encoders keep
+    them that way, and so do the flat parameter / gradient buffers) the concatenated table and its gradient are views:
+    no ``torch.cat`` in forward, no per-table slice-and-add in backward."""
 
     @staticmethod
-    def forward(ctx, idx, table, offsets):
+    def forward(ctx, idx, offsets, *weights):
+        table = adjacent_rows(weights)
+        if table is None:
+            table = torch.cat([w.detach() for w in weights], dim=0)
         ctx.save_for_backward(idx)
         ctx.offsets = tuple(offsets)
+        ctx.sinks = grad_sinks(weights)
         return ops.embed_sum_fwd(idx, table, offsets)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, ops.embed_sum_bwd(idx, ctx.offsets, dout.contiguous()), None
+        sinks, offs = ctx.sinks, ctx.offsets
+        if all(g is not None for g in sinks):
+            gtable = adjacent_rows(sinks)
+            if gtable is not None:  # accumulate straight into the tables' (flat) gradient buffer
+                ops.embed_sum_bwd(idx, offs, dout.contiguous(), out=gtable)
+                return (None, None) + (None,) * len(sinks)
+        dtable = ops.embed_sum_bwd(idx, offs, dout.contiguous())
+        return (None, None) + tuple(dtable[offs[k]:offs[k + 1]] for k in range(len(sinks)))
 
 
 class LinearFn(torch.autograd.Function):
@@ -103,9 +136,10 @@ class BatchNormFn(torch.autograd.Function):
     """torch.nn.BatchNorm1d (PyG BatchNorm wrapper; models.py:184, 212-214) with the following F.relu fused."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, nbt=None):
         x = x.contiguous()
-        y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu)
+        y, mean, rstd = ops.batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu,
+                                          num_batches_tracked=nbt)
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         ctx.relu, ctx.training = relu, training
         ctx.sinks = grad_sinks([gamma, beta])
@@ -119,7 +153,7 @@ class BatchNormFn(torch.autograd.Function):
         sg, sb = ctx.sinks
         dx, dgamma, dbeta = ops.batchnorm_bwd(dy.contiguous(), x, y, gamma, mean, rstd, ctx.relu, dgamma=sg, dbeta=sb)
         return dx, (None if sg is not None else dgamma), (None if sb is not None else dbeta), None, None, None, None, \
-            None, None
+            None, None, None
 
 
 class SegmentPoolFn(torch.autograd.Function):

@@ -51,11 +51,19 @@ class _Encoder(Module):
             offs.append(offs[-1] + d)
         self.offsets = tuple(offs)
 
-    def _tables(self) -> torch.Tensor:
-        return torch.cat([e.weight for e in getattr(self, self.list_name)], dim=0)
+    def _weights(self):
+        """The K tables, kept as consecutive row blocks of one buffer (re-packed after ``.to()`` / when something
+        re-pointed them) so that the concatenated table is a view; values and state-dict entries are unchanged."""
+        ws = [e.weight for e in getattr(self, self.list_name)]
+        if ws[0].is_cuda and Fn.adjacent_rows(ws) is None:
+            with torch.no_grad():
+                big = torch.cat([w.data for w in ws], dim=0)
+                for w, o0, o1 in zip(ws, self.offsets[:-1], self.offsets[1:]):
+                    w.data = big[o0:o1]
+        return ws
 
     def forward(self, idx: torch.Tensor) -> torch.Tensor:
-        return Fn.EmbedSumFn.apply(idx, self._tables(), self.offsets)
+        return Fn.EmbedSumFn.apply(idx, self.offsets, *self._weights())
 
 
 class AtomEncoder(_Encoder):
@@ -76,7 +84,7 @@ class BondEncoder(_Encoder):
         self.register_buffer("combos", combos, persistent=False)
 
     def table(self) -> torch.Tensor:
-        return Fn.EmbedSumFn.apply(self.combos, self._tables(), self.offsets)
+        return Fn.EmbedSumFn.apply(self.combos, self.offsets, *self._weights())
 
 
 class DegreeScalerAggregation(Module):
@@ -190,14 +198,19 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         use_batch_stats = self.training or not self.track_running_stats
         momentum = 0.0 if self.momentum is None else self.momentum
+        nbt = None
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
-            if self.momentum is None:
+            if self.momentum is None:  # cumulative average: the count is needed on the host (one sync, as in torch)
+                self.num_batches_tracked.add_(1)
                 momentum = 1.0 / float(self.num_batches_tracked)
+            elif self.num_batches_tracked.is_cuda and self.num_batches_tracked.dtype == torch.int64:
+                nbt = self.num_batches_tracked  # incremented by the kernel: no separate launch per layer
+            else:
+                self.num_batches_tracked.add_(1)
         return Fn.BatchNormFn.apply(x, self.weight, self.bias,
                                     self.running_mean if self.track_running_stats else None,
                                     self.running_var if self.track_running_stats else None, momentum, self.eps,
-                                    use_batch_stats, relu)
+                                    use_batch_stats, relu, nbt)
 
 
 class BatchNorm(Module):

@@ -225,12 +225,19 @@ def embed_sum_fwd(idx: torch.Tensor, table: torch.Tensor, offsets: Sequence[int]
     return out
 
 
-def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor) -> torch.Tensor:
+def embed_sum_bwd(idx: torch.Tensor, offsets: Sequence[int], dout: torch.Tensor,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient of the concatenated tables; ``out`` (fp32 [R,H], contiguous) is accumulated into (+=) when given."""
     K, R = len(offsets) - 1, offsets[-1]
     dout = _f32(dout, "dout").contiguous()
     idx = idx.contiguous()
     H = dout.size(1)
-    dtable = zeros(R, H, device=dout.device)
+    if out is not None:
+        if out.shape != (R, H) or not out.is_contiguous() or out.dtype is not torch.float32:
+            raise _lib.GnxError(_lib.GNX_E_INVALID, f"embed_sum_bwd: out must be contiguous fp32 [{R},{H}]")
+        dtable = out
+    else:
+        dtable = zeros(R, H, device=dout.device)
     lib = _lib.load()
     nbytes = lib.gnx_table_scatter_workspace_bytes(idx.size(0), R, H)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dout.device)
@@ -595,14 +602,17 @@ def _bn_ws(M: int, H: int, dev) -> Tuple[torch.Tensor, int]:
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
 
-def batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum: float, eps: float, training: bool, relu: bool):
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, momentum: float, eps: float, training: bool, relu: bool,
+                  num_batches_tracked: Optional[torch.Tensor] = None):
+    """``num_batches_tracked`` (int64[1] device tensor) is incremented by the kernel in training mode."""
     M, H = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(H, dtype=torch.float32, device=x.device)
     rstd = torch.empty(H, dtype=torch.float32, device=x.device)
     ws, nbytes = _bn_ws(M, H, x.device)
     check(_lib.load().gnx_batchnorm_fwd(handle(x.device), x.data_ptr(), M, H, _ptr(gamma), _ptr(beta),
-                                        _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                                        float(momentum), float(eps),
                                         int(training), int(relu), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                         ws.data_ptr(), nbytes))
     return y, mean, rstd

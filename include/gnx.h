@@ -244,10 +244,12 @@ int32_t gnx_segment_pool_bwd(gnx_handle* h, const float* dout, const float* x, c
 /* ---- BatchNorm1d (+ReLU) over rows (ref: train/models.py:184,212-214 and the readout mlp :186-194) ---------- */
 size_t gnx_batchnorm_workspace_bytes(int64_t M, int32_t H);
 /* training: batch statistics (biased var to normalise, unbiased into running_var, momentum), saves mean/rstd[H].
- * eval (training=0): uses running stats. y = relu?(gamma*(x-mean)*rstd + beta). */
+ * eval (training=0): uses running stats. y = relu?(gamma*(x-mean)*rstd + beta).  num_batches_tracked (device int64[1],
+ * may be NULL) is incremented in training mode, as torch.nn.BatchNorm1d does before the call. */
 int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, int32_t H, const float* gamma, const float* beta,
-                          float* running_mean, float* running_var, float momentum, float eps, int32_t training,
-                          int32_t relu, float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes);
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                          float eps, int32_t training, int32_t relu, float* y, float* save_mean, float* save_rstd,
+                          void* ws, size_t ws_bytes);
 /* dy masked by (y>0) when relu; dgamma/dbeta are ACCUMULATED (+=). */
 int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float* x, const float* y, int64_t M, int32_t H,
                           const float* gamma, const float* save_mean, const float* save_rstd, int32_t relu,
