@@ -1518,6 +1518,150 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
   wgrad_body<VEC, GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, Xs, Ys);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-operand weight gradient (same contract as wgrad_body<true, GROUPED> without a row scale; see the split-operand
+// notes at k_gemm_ws3).  dW[n,k] = sum_m dC[m,n] A[m,k] contracts over the ROW index of both operands, so both bf16
+// images must be column-major for the matrix core (a lane needs 8 consecutive m of one column).  The transpose is done
+// by the loader: thread = (column tid & 127, 16 rows), 16 four-byte loads per operand and 32-row step (each wave
+// instruction reads 256 contiguous bytes of one row); the 16 values of a column are split and stored with two
+// ds_write_b128 per image into [3][128 columns][32 m (+8 pad)] -- the same images and the same multiply loop as
+// k_gemm3.  The fp32-MFMA version above runs at ~70 TF and was the largest group of kernels of the step.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GROUPED>
+__device__ __forceinline__ void wgrad3_body(const wgrad_args& g, const int bx, const int by, const int bz,
+                                            unsigned char* A3, unsigned char* B3) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = by * BN;  // dW row tile (output features)
+  const int c0 = bz * BN;  // dW col tile (input features)
+  if (n0 >= g.N || c0 >= g.K) return;
+  int64_t r_begin = (int64_t)bx * g.rows_per_block;
+  int64_t r_end = r_begin + g.rows_per_block;
+  if (r_end > g.M) r_end = g.M;
+  float* dW = g.dW;
+  if constexpr (GROUPED) {
+    if (bx >= g.nchunks[0]) return;
+    r_begin = g.chunk_info[3 * bx];
+    r_end = r_begin + g.chunk_info[3 * bx + 1];
+    dW += (int64_t)g.chunk_info[3 * bx + 2] * g.dw_cls_stride;
+  }
+  if (r_begin >= r_end) return;  // (workgroup-uniform) nothing to contribute: skip the zero-valued atomic flush
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;  // column n0 + col of dC, this thread's 16-row half
+
+  const int col = tid & 127, rh = (tid >> 7) * 16;
+  const bool x_ok = n0 + col < g.N, y_ok = c0 + col < g.K;
+  const float* xp = g.X + (x_ok ? n0 + col : 0);
+  const float* yp = g.Y + (y_ok ? c0 + col : 0);
+  float gx[16], gy[16];
+  int nvalid = 0;  // valid rows among this thread's 16 of the tile in flight
+
+  auto load_tile = [&](int64_t r0) {
+    const int64_t first = r0 + rh;
+    const int64_t left = r_end - first;
+    nvalid = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t pos = first + j < r_end ? first + j : r_begin;  // clamped (r_begin < r_end here)
+      const int64_t row = GROUPED ? (int64_t)g.row_index[pos] : pos;
+      gx[j] = xp[row * g.ldx];
+      gy[j] = yp[row * g.ldy];
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int hgrp = 0; hgrp < 2; ++hgrp) {
+      float xa[8], ya[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = 8 * hgrp + j < nvalid;
+        xa[j] = (ok && x_ok) ? gx[8 * hgrp + j] : 0.f;
+        ya[j] = (ok && y_ok) ? gy[8 * hgrp + j] : 0.f;
+        bsum += xa[j];
+      }
+      bf16x8 p1, p2, p3;
+      split3(xa, p1, p2, p3);
+      unsigned char* q = A3 + col * G3_LDB + (rh + 8 * hgrp) * 2;
+      *reinterpret_cast<bf16x8*>(q) = p1;
+      *reinterpret_cast<bf16x8*>(q + G3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(q + 2 * G3_PIECE) = p3;
+      split3(ya, p1, p2, p3);
+      q = B3 + col * G3_LDB + (rh + 8 * hgrp) * 2;
+      *reinterpret_cast<bf16x8*>(q) = p1;
+      *reinterpret_cast<bf16x8*>(q + G3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(q + 2 * G3_PIECE) = p3;
+    }
+  };
+
+  int64_t r0 = r_begin;
+  load_tile(r0);
+  while (r0 < r_end) {
+    __syncthreads();  // previous multiply finished reading LDS
+    store_tile();
+    __syncthreads();
+    r0 += BK;
+    if (r0 < r_end) load_tile(r0);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[mi][p] = *reinterpret_cast<const bf16x8*>(A3 + p * G3_PIECE + (wm * 64 + mi * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[ni][p] = *reinterpret_cast<const bf16x8*>(B3 + p * G3_PIECE + (wn * 64 + ni * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      int gc = c0 + wn * 64 + ni * 32 + li;
+      if (gc >= g.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int gr = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (gr >= g.N) continue;
+        atomicAdd(dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
+      }
+    }
+  if (g.dbias != nullptr && bz == 0 && x_ok) atomicAdd(g.dbias + n0 + col, bsum);
+}
+
+template <bool GROUPED>
+__global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
+  __shared__ __attribute__((aligned(16))) unsigned char B3[G3_OP];
+  wgrad3_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, A3, B3);
+}
+
 // Several independent weight gradients in ONE launch (a layer's same-shaped dW = g^T a products): blockIdx.x =
 // problem * chunks + chunk.  With P problems sharing the grid every workgroup owns a P x longer row range, so the
 // per-problem atomic flush shrinks P x at equal parallelism (a lone 128x128 dW over 82k rows flushes 33 MB of fp32
@@ -1540,6 +1684,25 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad_batched(wgrad_batch_args 
   for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
     if (i == prob) g = b.p[i];
   wgrad_body<true, false>(g, chunk, blockIdx.y, blockIdx.z, Xs, Ys);
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_wgrad3_batched(wgrad_batch_args b) {
+  __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
+  __shared__ __attribute__((aligned(16))) unsigned char B3[G3_OP];
+  const int prob = blockIdx.x / b.chunks;
+  const int chunk = blockIdx.x - prob * b.chunks;
+  wgrad_args g = b.p[0];
+#pragma unroll
+  for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
+    if (i == prob) g = b.p[i];
+  wgrad3_body<false>(g, chunk, blockIdx.y, blockIdx.z, A3, B3);
+}
+
+// the split-operand weight-gradient kernels take over for large row counts (GNX_GEMM_SPLIT=0: fp32 MFMA everywhere)
+static bool wgrad_split_enabled(int64_t M, bool any_rowscale) {
+  if (any_rowscale || M < 4096) return false;
+  const char* e = getenv("GNX_GEMM_SPLIT");
+  return !(e && atoi(e) == 0);
 }
 
 static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
@@ -1585,7 +1748,12 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
     const char* e = getenv("GNX_WGRAD_VEC");
     if (e && atoi(e) == 0) vec = false;
   }
-  if (chunk_info) {
+  if (wgrad_split_enabled(M, rowscale != nullptr)) {
+    if (chunk_info)
+      hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm_wgrad3<false>), grid, dim3(256), 0, h->stream, g);
+  } else if (chunk_info) {
     if (vec)
       hipLaunchKernelGGL((k_gemm_wgrad<true, true>), grid, dim3(256), 0, h->stream, g);
     else
@@ -1725,7 +1893,12 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
   b.chunks = (int)chunks;
   dim3 grid((unsigned)(chunks * nprob), (unsigned)gnx_cdiv(maxN, BN), (unsigned)gnx_cdiv(maxK, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
-  hipLaunchKernelGGL(k_gemm_wgrad_batched, grid, dim3(256), 0, h->stream, b);
+  bool any_rs = false;
+  for (int i = 0; i < nprob; ++i) any_rs = any_rs || probs[i].rowscale != nullptr;
+  if (wgrad_split_enabled(maxM, any_rs))
+    hipLaunchKernelGGL(k_gemm_wgrad3_batched, grid, dim3(256), 0, h->stream, b);
+  else
+    hipLaunchKernelGGL(k_gemm_wgrad_batched, grid, dim3(256), 0, h->stream, b);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

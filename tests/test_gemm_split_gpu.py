@@ -123,3 +123,69 @@ def test_split_and_exact_kernels_agree(gpu_device):
     assert rel_err(outs["1"], ref) <= TOL and rel_err(outs["0"], ref) <= TOL
     assert rel_err(outs["1"], outs["0"]) <= 2e-6
     assert rel_err(outs["1"], ref) <= rel_err(outs["0"], ref) * 1.5 + 1e-8
+
+
+@pytest.mark.parametrize("M,N,K", [(20001, 128, 128), (8192, 36, 100), (5000, 130, 260)])
+def test_split_weight_gradient_single(gpu_device, M, N, K):
+    """dW += dC^T A and db += column sums on the split-operand kernel (no row scale, M >= 4096): ragged shapes, strided
+    views, accumulation into existing values."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(M + N)
+    wide_dc, wide_a = torch.randn(M, N + 8), torch.randn(M, K + 12)
+    dc, a = wide_dc[:, 4:4 + N], wide_a[:, 8:8 + K]
+    dcd, ad = wide_dc.to(gpu_device)[:, 4:4 + N], wide_a.to(gpu_device)[:, 8:8 + K]
+    dw = torch.full((N, K), 2.0, device=gpu_device)
+    db = torch.full((N,), -1.0, device=gpu_device)
+    ops.gemm_wgrad(dcd, ad, dw, dbias=db)
+    assert rel_err(dw, 2.0 + dc.double().T @ a.double()) <= TOL
+    assert rel_err(db, -1.0 + dc.double().sum(0)) <= TOL
+
+
+def test_split_weight_gradient_batched(gpu_device):
+    """A layer's worth of independent weight gradients in one launch (different M, shared operands)."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(12)
+    F = 128
+    Mn, Me = 9000, 18000
+    g = [torch.randn(Mn, F) for _ in range(4)] + [torch.randn(Me, F)]
+    x = [torch.randn(Mn, F) for _ in range(4)] + [torch.randn(Me, F)]
+    dws = [torch.zeros(F, F, device=gpu_device) for _ in range(5)]
+    dbs = [torch.zeros(F, device=gpu_device) for _ in range(5)]
+    gd = [t.to(gpu_device) for t in g]
+    xd = [t.to(gpu_device) for t in x]
+    for i in range(5):
+        ops.queue_wgrad(gd[i], xd[i], dws[i], dbias=dbs[i] if i % 2 == 0 else None)
+    ops.queue_wgrad(gd[0], xd[1], dws[1])  # a second contribution to the same dW
+    ops.flush_wgrads()
+    ops.join_side_stream(gpu_device)
+    for i in range(5):
+        ref = g[i].double().T @ x[i].double()
+        if i == 1:
+            ref = ref + g[0].double().T @ x[1].double()
+        assert rel_err(dws[i], ref) <= TOL, i
+        if i % 2 == 0:
+            assert rel_err(dbs[i], g[i].double().sum(0)) <= TOL, i
+        else:
+            assert float(dbs[i].abs().max()) == 0.0
+
+
+def test_split_weight_gradient_by_degree_class(gpu_device):
+    """Post-layer-0 weight gradient through per-degree-class partial sums (gathered rows, K = 4F wide)."""
+    from gnnepcsaft_amd import ops
+    rng = np.random.default_rng(41)
+    N, E, F = 60000, 150000, 64
+    ei = _graph(rng, N, E)
+    g = _pack(ei, None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    assert dc is not None
+    avg = 1.15
+    amp, att = g.degree_scalers(avg)
+    torch.manual_seed(8)
+    gr, A = torch.randn(N, F), torch.randn(N, 4 * F)
+    cat = torch.cat([torch.zeros(N, F), A, A * amp.cpu()[:, None], A * att.cpu()[:, None]], 1).double()
+    ref = gr.double().T @ cat
+    dW = torch.zeros(F, 13 * F, device=gpu_device)
+    ops.pna_post0_wgrad_classes(gr.to(gpu_device), A.to(gpu_device), dc, F, avg, dW)
+    ops.join_side_stream(gpu_device)
+    assert rel_err(dW[:, F:], ref[:, F:]) <= TOL
+    assert float(dW[:, :F].abs().max()) == 0.0
