@@ -779,6 +779,12 @@ __global__ void __launch_bounds__(256) k_split_weights(split_args g) {
 // invalid tile ends the walk.  The loads of the next tile (its row ids, then its first K-tile) are issued while the
 // current tile is still multiplying, so a workgroup waits on a cold pipeline only once.
 //
+// Where a workgroup's time goes (s_memtime stamps around the phases, post-layer-0 shape, 25 K-tiles per workgroup on
+// average): issuing the 10 loads of a K-tile 20 % (the waves stall AT the load instructions: 40 KB per K-tile through
+// the CU's 64 B/clk vector-memory path, shared by both resident workgroups), split + LDS store incl. the wait for the
+// data 22 %, LDS reads + MFMA issue 17 % + 7 % waiting for the other waves' MFMAs at the barrier, epilogue 6 %, tile
+// switch / prologue the rest.  The phases of one workgroup are serial; only the two resident workgroups overlap.
+//
 // Measured dead ends on MI355X (kept out of the code, recorded here): a 512-thread double-buffered variant with
 // hand-counted inline-asm loads, the same with the loads interleaved between MFMAs, and a loader/multiply
 // wave-specialised variant were all correct and all 3-20 % SLOWER than this two-barrier form; their phase ablations
@@ -870,21 +876,37 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   f32x4 rb[6];   // B K-tile of the next stage: six 16-byte words of the contiguous [3][128][32] bf16 block
   int kvalid_a = 0;  // per-pass validity bits of ra, applied at store time
 
-  auto load_ab = [&](int s_i, int k0, const int (&gr)[4], int cl, int nn0) {
+  // Load cursor state kept in registers: indexing g.seg[] / g.koff[] with a run-time index is a kernarg load + wait,
+  // and the row byte offsets are 64-bit multiplies -- both are paid when the segment (or tile) changes, not per K-tile
+  // (measured with s_memtime: the "issue the loads" phase was 24 % of the workgroup's lifetime before this).
+  const float* rowp[4];   // this thread's four A rows in the current segment (k = 0)
+  int rowv = 0;           // validity bits of the four rows
+  int segK = 0;
+  const __bf16* bptr = nullptr;  // this thread's 16-byte slot in the B block of the cursor's K-tile
+  auto enter_segment = [&](int s_i, const int (&gr)[4]) {
     const seg_dev& s = g.seg[s_i];
-    const int k = k0 + lk4;
-    const bool k_ok = k < s.k;
-    const float* ap = s.a + (k_ok ? k : 0);
-    kvalid_a = 0;
+    rowv = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t arow = gr[q] >= 0 ? gr[q] : 0;
-      ra[q] = *reinterpret_cast<const f32x4*>(ap + arow * s.lda);
-      kvalid_a |= (k_ok && gr[q] >= 0) ? (1 << q) : 0;
+      rowp[q] = s.a + (int64_t)(gr[q] >= 0 ? gr[q] : 0) * s.lda;
+      rowv |= gr[q] >= 0 ? (1 << q) : 0;
     }
-    const __bf16* bq = g.bsplit + ((((int64_t)cl * NT + nn0 / BN) * KT + (g.koff[s_i] + k0) / BK) * 3) * (BN * BK) + tid * 8;
+    segK = s.k;
+  };
+  auto enter_tile = [&](const int (&gr)[4], int cl, int nn0) {
+    enter_segment(0, gr);
+    bptr = g.bsplit + (((int64_t)cl * NT + nn0 / BN) * KT * 3) * (BN * BK) + tid * 8;
+  };
+  auto load_ab = [&](int k0) {  // K-tile at (current segment, k0); the B blocks of a tile are consecutive
+    const int k = k0 + lk4;
+    const bool k_ok = k < segK;
+    const int kc = k_ok ? k : 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bq + j * 2048);
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(rowp[q] + kc);
+    kvalid_a = k_ok ? rowv : 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bptr + j * 2048);
+    bptr += 3 * (BN * BK);
   };
 
   typedef __attribute__((ext_vector_type(2))) float f32x2;  // 8-byte LDS word (four bf16)
@@ -952,22 +974,26 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   fetch_bias(n0);
 
   int s1 = 0, k1 = 0;  // (segment, k) of the K-tile held in ra / rb
-  load_ab(0, 0, grow, cls, n0);
+  enter_tile(grow, cls, n0);
+  load_ab(0);
   while (true) {
     __syncthreads();  // previous multiply finished reading LDS
     store_tile();
     __syncthreads();
     // advance to the next K-tile; past the last segment it is the next tile's first K-tile
     k1 += BK;
-    if (k1 >= g.seg[s1].k) {
+    bool last = false;
+    if (k1 >= segK) {
       ++s1;
       k1 = 0;
+      last = s1 >= g.nseg;
+      if (!last) enter_segment(s1, grow);
     }
-    const bool last = s1 >= g.nseg;
     if (!last) {
-      load_ab(s1, k1, grow, cls, n0);
+      load_ab(k1);
     } else if (valid_n) {
-      load_ab(0, 0, grow_n, cls_n, n0_n);
+      enter_tile(grow_n, cls_n, n0_n);
+      load_ab(0);
     }
     compute();
     if (!last) continue;
