@@ -1555,7 +1555,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad(wgrad_args g) {
 // ---------------------------------------------------------------------------------------------------------------
 template <bool GROUPED>
 __device__ __forceinline__ void wgrad3_body(const wgrad_args& g, const int bx, const int by, const int bz,
-                                            unsigned char* A3, unsigned char* B3) {
+                                            unsigned char* A3, unsigned char* B3, unsigned* offs) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1592,16 +1592,46 @@ __device__ __forceinline__ void wgrad3_body(const wgrad_args& g, const int bx, c
   float gx[16], gy[16];
   int nvalid = 0;  // valid rows among this thread's 16 of the tile in flight
 
-  auto load_tile = [&](int64_t r0) {
+  // GROUPED: rows are gathered through row_index.  The element offsets row * ld of a step's 32 rows are computed once
+  // per workgroup (threads 0..31, two steps ahead, into a double-buffered LDS array offs[parity][X|Y][32]) instead of
+  // 32 index loads + 32 64-bit multiplies per thread and step; the host guarantees M * ld < 2^32.
+  auto stage_offsets = [&](int64_t r0, int par) {
+    if constexpr (GROUPED) {
+      if (tid < 32) {
+        const int64_t pos = r0 + tid < r_end ? r0 + tid : r_begin;
+        const unsigned row = (unsigned)g.row_index[pos];
+        offs[par * 64 + tid] = row * (unsigned)g.ldx;
+        offs[par * 64 + 32 + tid] = row * (unsigned)g.ldy;
+      }
+    }
+  };
+  auto load_tile = [&](int64_t r0, int par) {
     const int64_t first = r0 + rh;
     const int64_t left = r_end - first;
     nvalid = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+    if constexpr (GROUPED) {
+      const unsigned* ox = offs + par * 64 + rh;
+      const unsigned* oy = ox + 32;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int64_t pos = first + j < r_end ? first + j : r_begin;  // clamped (r_begin < r_end here)
-      const int64_t row = GROUPED ? (int64_t)g.row_index[pos] : pos;
-      gx[j] = xp[row * g.ldx];
-      gy[j] = yp[row * g.ldy];
+      for (int j = 0; j < 16; ++j) {
+        gx[j] = xp[ox[j]];
+        gy[j] = yp[oy[j]];
+      }
+    } else if (r0 + BK <= r_end) {  // full step (workgroup-uniform): one 64-bit product per operand, uniform strides
+      const float* xb = xp + first * g.ldx;
+      const float* yb = yp + first * g.ldy;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        gx[j] = xb[j * g.ldx];
+        gy[j] = yb[j * g.ldy];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int64_t row = first + j < r_end ? first + j : r_begin;  // clamped (r_begin < r_end here)
+        gx[j] = xp[row * g.ldx];
+        gy[j] = yp[row * g.ldy];
+      }
     }
   };
 
@@ -1631,13 +1661,20 @@ __device__ __forceinline__ void wgrad3_body(const wgrad_args& g, const int bx, c
   };
 
   int64_t r0 = r_begin;
-  load_tile(r0);
+  int par = 0;
+  stage_offsets(r0, 0);
+  stage_offsets(r0 + BK, 1);
+  if constexpr (GROUPED) __syncthreads();
+  load_tile(r0, 0);
   while (r0 < r_end) {
-    __syncthreads();  // previous multiply finished reading LDS
+    __syncthreads();  // previous multiply finished reading LDS (and the offsets staged during it are visible)
     store_tile();
     __syncthreads();
     r0 += BK;
-    if (r0 < r_end) load_tile(r0);
+    par ^= 1;
+    if (r0 < r_end) load_tile(r0, par);
+    // offsets of the step after that one go into the other buffer (last read one step ago, two barriers back)
+    if (r0 + BK < r_end) stage_offsets(r0 + BK, par ^ 1);
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       bf16x8 a[2][3], b[2][3];
@@ -1685,7 +1722,8 @@ template <bool GROUPED>
 __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
   __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
   __shared__ __attribute__((aligned(16))) unsigned char B3[G3_OP];
-  wgrad3_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, A3, B3);
+  __shared__ __attribute__((aligned(16))) unsigned offs[128];
+  wgrad3_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, A3, B3, offs);
 }
 
 // Several independent weight gradients in ONE launch (a layer's same-shaped dW = g^T a products): blockIdx.x =
@@ -1721,7 +1759,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3_batched(wgrad_batch_args
 #pragma unroll
   for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
     if (i == prob) g = b.p[i];
-  wgrad3_body<false>(g, chunk, blockIdx.y, blockIdx.z, A3, B3);
+  wgrad3_body<false>(g, chunk, blockIdx.y, blockIdx.z, A3, B3, nullptr);
 }
 
 // the split-operand weight-gradient kernels take over for large row counts (GNX_GEMM_SPLIT=0: fp32 MFMA everywhere)
@@ -1774,7 +1812,8 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
     const char* e = getenv("GNX_WGRAD_VEC");
     if (e && atoi(e) == 0) vec = false;
   }
-  if (wgrad_split_enabled(M, rowscale != nullptr)) {
+  const bool offs32 = (uint64_t)M * (uint64_t)lddc < (1ull << 32) && (uint64_t)M * (uint64_t)lda < (1ull << 32);
+  if (wgrad_split_enabled(M, rowscale != nullptr) && (!chunk_info || offs32)) {
     if (chunk_info)
       hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
     else
