@@ -569,10 +569,11 @@ def gine_aggregate_bwd(dout: torch.Tensor, x: torch.Tensor, Le: torch.Tensor, g:
                        eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     dx = torch.empty_like(x)
     dLe = zeros(*Le.shape, device=Le.device)
+    pos = g.code_index(Le.size(0)) if g.E > 0 else None  # inverted index by bond code (None above 64 codes)
     check(_lib.load().gnx_gine_aggregate_bwd(handle(x.device), dout.data_ptr(), x.data_ptr(), Le.data_ptr(),
                                              g.colptr.data_ptr(), g.cpos.data_ptr(), g.src.data_ptr(),
-                                             g.dst.data_ptr(), g.code.data_ptr(), g.N, g.E, x.size(1), Le.size(0),
-                                             float(eps), dx.data_ptr(), dLe.data_ptr()))
+                                             g.dst.data_ptr(), g.code.data_ptr(), _ptr(pos), g.N, g.E, x.size(1),
+                                             Le.size(0), float(eps), dx.data_ptr(), dLe.data_ptr()))
     return dx, dLe
 
 

@@ -228,11 +228,12 @@ int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, co
 int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const float* Le, const int32_t* rowptr,
                                const int32_t* src, const int32_t* code, int64_t N, int32_t H, float eps, float* out);
 /* dx[j,:] = (1+eps) dout[j,:] + sum_{p in cpos(j)} dout[dst[p],:] * (x[j,:] + Le[code[p],:] > 0);
- * dLe[R,H] (optional) += sum_p [code[p]==r] dout[dst[p],:] * (x[src[p],:] + Le[r,:] > 0), LDS-privatised. */
+ * dLe[R,H] (optional) += sum_p [code[p]==r] dout[dst[p],:] * (x[src[p],:] + Le[r,:] > 0); code_pos (optional) =
+ * CSR positions stably grouped by code (gnx_group_by_small_key): register sums per key run instead of LDS atomics. */
 int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, const float* x, const float* Le,
                                const int32_t* colptr, const int32_t* cpos, const int32_t* src, const int32_t* dst,
-                               const int32_t* code, int64_t N, int64_t E, int32_t H, int32_t R, float eps, float* dx,
-                               float* dLe);
+                               const int32_t* code, const int32_t* code_pos, int64_t N, int64_t E, int32_t H, int32_t R,
+                               float eps, float* dx, float* dLe);
 
 /* ---- contiguous segment reduce: global pool (ref: train/models.py:218-225, 587-595) ------------------------ */
 enum { GNX_POOL_ADD = 0, GNX_POOL_MEAN = 1, GNX_POOL_MAX = 2 };
