@@ -224,7 +224,8 @@ def main():
                                  "achieved": (alg_b / (ms_b / max(n_b, 1) * 1e-3) / 1e9) if n_b else 0.0}},
             "mfma": {"ref_flops_per_graph_fwd_bwd": flops, "peak_tflops": MFMA_F32_PEAK_TF,
                      "arithmetic": "fp32 operands as three bf16 pieces, six bf16 MFMAs per product, fp32 accumulation "
-                                   "(GNX_GEMM_SPLIT=0 selects the exact-fp32 MFMA kernels); weight gradients: fp32 MFMA",
+                                   "(products and weight gradients with >= 4096 rows; GNX_GEMM_SPLIT=0 selects the "
+                                   "exact-fp32 MFMA kernels)",
                      # reference-formulation FLOPs delivered per second, as a fraction of the fp32-MFMA peak: the
                      # restructured layers do fewer FLOPs than the reference formulation, so this is a speed ratio
                      "model_frac_of_f32_mfma_peak": (flops * value / world / 1e12 / MFMA_F32_PEAK_TF) if flops else None,
