@@ -1,0 +1,90 @@
+"""Inference engine: BatchNorm folded into the preceding Linear, weight-only tables precomputed.
+Against the CPU oracle in eval mode and against the unfolded native model, PNA (with towers) and GINE, batched and
+``batch=None`` single-molecule form, ``pred_with_bounds`` clipping, hub-heavy fallback."""
+import copy
+
+import pytest
+import torch
+
+from tests.parity_util import make_models, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _trained_like(cfg, batch):
+    """Oracle / native pair with non-trivial running statistics and BN affine parameters."""
+    oracle, native = make_models(cfg)
+    torch.manual_seed(3)
+    for m in oracle.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+    oracle.train()
+    for _ in range(2):
+        oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    native.load_state_dict(oracle.state_dict())
+    oracle.eval()
+    native.eval().to("cuda:0")
+    return oracle, native
+
+
+@pytest.mark.parametrize("kw", [dict(hidden_dim=64, propagation_depth=3),
+                                dict(hidden_dim=128, towers=4, propagation_depth=2, pre_layers=1, post_layers=2),
+                                dict(conv="GINE", hidden_dim=64, propagation_depth=3, global_pool="mean"),
+                                dict(hidden_dim=32, propagation_depth=2, global_pool="max", num_para=2)])
+def test_engine_matches_eval_model_and_oracle(gpu_device, kw):
+    from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
+    from gnnepcsaft_amd.inference import InferenceEngine
+    cfg = default_config(2)
+    cfg.update(kw)
+    batch = synthetic_batch(48, 2)
+    cfg["deg"] = calc_deg(batch)
+    oracle, native = _trained_like(cfg, batch)
+    eng = InferenceEngine(native)
+    bd = batch.to("cuda:0")
+    with torch.no_grad():
+        ref = oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+        nat = native(bd.x, bd.edge_index, bd.edge_attr, bd.batch)
+    out = eng(bd.x, bd.edge_index, bd.edge_attr, bd.batch)
+    assert out.shape == ref.shape
+    assert rel_err(out, nat) <= 1e-5, "folded engine vs unfolded native eval model"
+    assert rel_err(out, ref) <= 2e-5, "folded engine vs CPU oracle in eval mode"
+    # single molecule, batch=None (demo/utils.py:950), and the clipped form
+    one = batch.to_data_list()[5].to("cuda:0")
+    with torch.no_grad():
+        ref1 = oracle(one.x.cpu(), one.edge_index.cpu(), one.edge_attr.cpu(), None)
+        refb = oracle.pred_with_bounds(batch)
+    assert rel_err(eng(one.x, one.edge_index, one.edge_attr, None), ref1) <= 2e-5
+    assert rel_err(eng.pred_with_bounds(bd), refb) <= 2e-5
+    with pytest.raises(ValueError):
+        bad = copy.copy(bd)
+        bad.x = None
+        eng.pred_with_bounds(bad)
+
+
+def test_engine_large_batch_and_hub_fallback(gpu_device):
+    """>= 8192 atoms (large-batch kernels) and a batch with > 64 distinct in-degrees (ungrouped post-layer 0)."""
+    from gnnepcsaft_amd.data import Batch, Data, calc_deg, default_config, synthetic_batch
+    from gnnepcsaft_amd.inference import InferenceEngine
+    cfg = default_config(2)
+    cfg.update(hidden_dim=128, propagation_depth=2)
+    batch = synthetic_batch(512, 2)
+    cfg["deg"] = calc_deg(batch)
+    oracle, native = _trained_like(cfg, synthetic_batch(64, 2))
+    eng = InferenceEngine(native)
+    bd = batch.to("cuda:0")
+    with torch.no_grad():
+        ref = oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    assert rel_err(eng(bd.x, bd.edge_index, bd.edge_attr, bd.batch), ref) <= 1e-4
+    # a star graph with 100 leaves: in-degree 100 on the hub -> no degree classes
+    n = 101
+    src = torch.arange(1, n)
+    ei = torch.stack([torch.cat([src, torch.zeros(n - 1, dtype=torch.long)]),
+                      torch.cat([torch.zeros(n - 1, dtype=torch.long), src])])
+    star = Data(x=batch.x[:n].clone(), edge_index=ei, edge_attr=batch.edge_attr[:2 * (n - 1)].clone(),
+                para=torch.ones(1, 3), assoc=torch.ones(1, 2))
+    mixed = Batch.from_data_list([star] + batch.to_data_list()[:3])
+    with torch.no_grad():
+        ref_m = oracle(mixed.x, mixed.edge_index, mixed.edge_attr, mixed.batch)
+    md = mixed.to("cuda:0")
+    assert rel_err(eng(md.x, md.edge_index, md.edge_attr, md.batch), ref_m) <= 1e-4
