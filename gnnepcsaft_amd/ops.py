@@ -202,7 +202,7 @@ def pack_graph(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], batc
     else:
         g.B = 1
         g.has_batch = False
-        g.graph_ptr = torch.tensor([0, N], **i32)
+        g.graph_ptr = torch.arange(2, **i32) * N  # [0, N] built on the device (capturable; no host-to-device copy)
     if validate:
         check_range(dev)
     return g

@@ -88,3 +88,23 @@ def test_engine_large_batch_and_hub_fallback(gpu_device):
         ref_m = oracle(mixed.x, mixed.edge_index, mixed.edge_attr, mixed.batch)
     md = mixed.to("cuda:0")
     assert rel_err(eng(md.x, md.edge_index, md.edge_attr, md.batch), ref_m) <= 1e-4
+
+
+def test_single_molecule_graph_replay(gpu_device):
+    """``engine.single``: per-shape HIP graph; equals the eager engine bit for bit, across shapes and repeated calls."""
+    from gnnepcsaft_amd import ops
+    from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
+    from gnnepcsaft_amd.inference import InferenceEngine
+    cfg = default_config(2)
+    cfg.update(hidden_dim=64, propagation_depth=3)
+    batch = synthetic_batch(24, 5)  # 5..80 atoms: several shapes
+    cfg["deg"] = calc_deg(batch)
+    _, native = _trained_like(cfg, synthetic_batch(32, 2))
+    eng = InferenceEngine(native, max_degree=len(cfg["deg"]) - 1)
+    mols = [m.to("cuda:0") for m in batch.to_data_list()]
+    for rep in range(2):
+        for m in mols[:10]:
+            eager = eng(m.x, m.edge_index, m.edge_attr, None, validate=False).clone()
+            replay = eng.single(m.x, m.edge_index, m.edge_attr).clone()
+            assert torch.equal(eager, replay)
+    ops.check_range(torch.device("cuda:0"))

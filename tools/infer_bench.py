@@ -27,7 +27,10 @@ for cfg_i, graphs in ((2, 4096), (2, 1), (3, 16384)):
     def run_engine():
         return eng(b.x, b.edge_index, b.edge_attr, batch_arg, validate=False)
 
-    for name, fn in (("model.eval()", run_model), ("InferenceEngine", run_engine)):
+    runs = [("model.eval()", run_model), ("InferenceEngine", run_engine)]
+    if graphs == 1:
+        runs.append(("engine.single (HIP graph)", lambda: eng.single(b.x, b.edge_index, b.edge_attr)))
+    for name, fn in runs:
         for _ in range(5): fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -35,5 +38,5 @@ for cfg_i, graphs in ((2, 4096), (2, 1), (3, 16384)):
         for _ in range(n): fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"cfg-{cfg_i} {graphs:6d} graphs  {name:16s} {dt*1e3:8.3f} ms/call  {graphs/dt:12.0f} graphs/s", flush=True)
+        print(f"cfg-{cfg_i} {graphs:6d} graphs  {name:26s} {dt*1e3:8.3f} ms/call  {graphs/dt:12.0f} graphs/s", flush=True)
     ops.check_range(dev)
