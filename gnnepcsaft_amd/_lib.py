@@ -3,7 +3,6 @@ load, importing the compute path raises — the product never routes through a C
 from __future__ import annotations
 
 import ctypes as C
-import os
 from pathlib import Path
 from typing import Dict, Optional
 

@@ -7,9 +7,8 @@ with the oracle's collate (tests/test_batching.py).  The device-side CSR packing
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence
+from typing import Iterable, List, Sequence
 
-import numpy as np
 import torch
 
 # vocabulary sizes = embedding-table rows (/root/reference/gnnepcsaft/data/ogb_utils.py:8-34)

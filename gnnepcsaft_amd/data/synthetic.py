@@ -8,7 +8,7 @@ sizes; both bond directions adjacent, ``ogb_utils.py:125-129``; empty graphs hav
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 import torch

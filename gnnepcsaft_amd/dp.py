@@ -10,7 +10,7 @@ CPU tests of this logic.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist

@@ -6,7 +6,7 @@ reference wires at ``/root/reference/gnnepcsaft/train/models.py``.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 

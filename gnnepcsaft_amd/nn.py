@@ -8,11 +8,10 @@ Attribute and state-dict names follow upstream so that reference checkpoints' ``
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional, Sequence
 
 import torch
-from torch.nn import Module, ModuleList, Parameter
+from torch.nn import Module, ModuleList
 
 from . import functional as Fn
 from .data.batching import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
