@@ -1737,32 +1737,58 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
 struct wgrad_batch_args {
   wgrad_args p[WGRAD_MAX_BATCH];
   int nprob;
-  int chunks;
+  // 1-D work list: problem i owns workgroups [wg_off[i], wg_off[i+1]) = its row chunks x its 128x128 output tiles.
+  // Chunk counts are per problem (proportional to its share of the work): one uniform count starved the small
+  // problems of a batch that also held a 512x512 one (cfg-5: 32 workgroups busy on 256 CUs, 26 TF).
+  int wg_off[WGRAD_MAX_BATCH + 1];
+  int tiles_k[WGRAD_MAX_BATCH];  // column tiles of dW
+  int tiles[WGRAD_MAX_BATCH];    // row tiles x column tiles of dW
 };
+
+// (problem, chunk, dW row tile, dW column tile) of a workgroup of the 1-D batched grid
+__device__ __forceinline__ void wgrad_batch_locate(const wgrad_batch_args& b, int w, int& prob, int& chunk, int& by,
+                                                   int& bz) {
+  prob = 0;
+#pragma unroll
+  for (int i = 1; i < WGRAD_MAX_BATCH; ++i) prob += (i < b.nprob && w >= b.wg_off[i]) ? 1 : 0;
+  int off = b.wg_off[0], tiles = b.tiles[0], tk = b.tiles_k[0];
+#pragma unroll
+  for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
+    if (i == prob) {
+      off = b.wg_off[i];
+      tiles = b.tiles[i];
+      tk = b.tiles_k[i];
+    }
+  const int local = w - off;
+  chunk = local / tiles;
+  const int t = local - chunk * tiles;
+  by = t / tk;
+  bz = t - by * tk;
+}
 
 __global__ void __launch_bounds__(256, 2) k_gemm_wgrad_batched(wgrad_batch_args b) {
   __shared__ __attribute__((aligned(16))) float Xs[BK * LDN];
   __shared__ __attribute__((aligned(16))) float Ys[BK * LDN];
-  const int prob = blockIdx.x / b.chunks;
-  const int chunk = blockIdx.x - prob * b.chunks;
+  int prob, chunk, by, bz;
+  wgrad_batch_locate(b, blockIdx.x, prob, chunk, by, bz);
   // copy the selected descriptor (wave-uniform index) so the body sees scalars
   wgrad_args g = b.p[0];
 #pragma unroll
   for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
     if (i == prob) g = b.p[i];
-  wgrad_body<true, false>(g, chunk, blockIdx.y, blockIdx.z, Xs, Ys);
+  wgrad_body<true, false>(g, chunk, by, bz, Xs, Ys);
 }
 
 __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3_batched(wgrad_batch_args b) {
   __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
   __shared__ __attribute__((aligned(16))) unsigned char B3[G3_OP];
-  const int prob = blockIdx.x / b.chunks;
-  const int chunk = blockIdx.x - prob * b.chunks;
+  int prob, chunk, by, bz;
+  wgrad_batch_locate(b, blockIdx.x, prob, chunk, by, bz);
   wgrad_args g = b.p[0];
 #pragma unroll
   for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
     if (i == prob) g = b.p[i];
-  wgrad3_body<false>(g, chunk, blockIdx.y, blockIdx.z, A3, B3, nullptr);
+  wgrad3_body<false>(g, chunk, by, bz, A3, B3, nullptr);
 }
 
 // the split-operand weight-gradient kernels take over for large row counts (GNX_GEMM_SPLIT=0: fp32 MFMA everywhere)
@@ -1950,16 +1976,34 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
   }
   for (int i = nprob; i < WGRAD_MAX_BATCH; ++i) b.p[i] = b.p[0];
   if (maxM == 0) return GNX_OK;
-  const int64_t tiles = gnx_cdiv(maxN, BN) * gnx_cdiv(maxK, BN);
-  int64_t chunks = gnx_cdiv(512, tiles * nprob);
-  if (chunks < 1) chunks = 1;
-  for (int i = 0; i < nprob; ++i) {
-    int64_t rows = gnx_cdiv(gnx_cdiv(b.p[i].M > 0 ? b.p[i].M : 1, chunks), BK) * BK;
-    b.p[i].rows_per_block = rows;  // chunks whose range starts beyond M do nothing
+  // ~1024 workgroups in total, shared out by work (rows x output tiles); every chunk is a multiple of 32 rows
+  double total_cost = 0.0;
+  for (int i = 0; i < nprob; ++i)
+    total_cost += (double)b.p[i].M * (double)(gnx_cdiv(b.p[i].N, BN) * gnx_cdiv(b.p[i].K, BN));
+  int off = 0;
+  for (int i = 0; i < WGRAD_MAX_BATCH; ++i) {
+    b.wg_off[i] = off;
+    b.tiles[i] = 1;
+    b.tiles_k[i] = 1;
+    if (i >= nprob) continue;
+    const int tn = (int)gnx_cdiv(b.p[i].N, BN), tk = (int)gnx_cdiv(b.p[i].K, BN);
+    const int64_t M = b.p[i].M > 0 ? b.p[i].M : 1;
+    static const double budget = []() { const char* e = getenv("GNX_WGRAD_WGS"); return e ? atof(e) : 1024.0; }();
+    int64_t chunks = (int64_t)(budget * ((double)M * tn * tk / total_cost) / (tn * tk) + 0.5);
+    const int64_t max_chunks = gnx_cdiv(M, 128);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    const int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
+    chunks = gnx_cdiv(M, rows);  // no empty chunks
+    b.p[i].rows_per_block = rows;
+    b.tiles[i] = tn * tk;
+    b.tiles_k[i] = tk;
+    off += (int)chunks * tn * tk;
   }
+  b.wg_off[WGRAD_MAX_BATCH] = off;
+  for (int i = nprob; i < WGRAD_MAX_BATCH; ++i) b.wg_off[i] = off;
   b.nprob = nprob;
-  b.chunks = (int)chunks;
-  dim3 grid((unsigned)(chunks * nprob), (unsigned)gnx_cdiv(maxN, BN), (unsigned)gnx_cdiv(maxK, BN));
+  dim3 grid((unsigned)off);
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   bool any_rs = false;
   for (int i = 0; i < nprob; ++i) any_rs = any_rs || probs[i].rowscale != nullptr;
