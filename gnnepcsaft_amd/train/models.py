@@ -22,6 +22,10 @@ from ..ops import GraphPack
 from .lightning_lite import LightningModuleLite
 
 _OUT_OF_SCOPE_CONVS = ("GCN", "GAT", "GATv2", "Transformer", "SAGE", "GIN", "Edge", "GatedGraph", "Graph", "ARMA", "SG")
+_ASSOC_DATASETS = ("esper_assoc", "esper_assoc_only")  # datasets whose label is ``graphs.assoc`` (reference :80-87)
+# parameter bounds (reference :167-172): m, sigma, epsilon/k | log10 kappa_ab (negated), log10 epsilon_ab
+_LOWER = (1.0, 1.9, 50.0, -math.log10(0.9), math.log10(200.0))
+_UPPER = (25.0, 4.5, 550.0, -math.log10(0.0001), math.log10(5000.0))
 
 
 def _pack_of(graphs, validate: bool, max_degree_hint: Optional[int] = None) -> GraphPack:
@@ -41,117 +45,99 @@ def _pack_of(graphs, validate: bool, max_degree_hint: Optional[int] = None) -> G
 
 
 class GNNePCSAFTL(LightningModuleLite):
-    """Graph neural network to predict PCSAFT parameters (Lightning-style wrapper; reference :23-156)."""
+    """Lightning-style wrapper around ``GNNePCSAFT`` (reference :23-156): ``.model``, ``.config``, ``training_step``,
+    ``validation_step`` / ``test_step``, ``configure_optimizers``."""
 
     def __init__(self, config: dict[str, Any]):
         super().__init__()
         self.save_hyperparameters()
-        self.config = config
-        self.model = GNNePCSAFT(config)
+        self.config, self.model = config, GNNePCSAFT(config)
         # hooks for the CPU PC-SAFT label oracle (feos), which stays outside this package (north star)
-        self.rho_batch = None
-        self.vp_batch = None
+        self.rho_batch = self.vp_batch = None
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
                 batch: torch.Tensor, pack: Optional[GraphPack] = None) -> torch.Tensor:
-        """Forward pass of the model"""
         return self.model(x, edge_index, edge_attr, batch, pack=pack)
 
     def configure_optimizers(self):
-        if self.config["optimizer"] == "adam":
-            opt = torch.optim.AdamW(self.parameters(), lr=self.config["learning_rate"],
-                                    weight_decay=self.config["weight_decay"], amsgrad=True, eps=1e-5)
-        elif self.config["optimizer"] == "sgd":
-            opt = torch.optim.SGD(self.parameters(), lr=self.config["learning_rate"], momentum=0.0, weight_decay=0.0,
+        """AdamW(amsgrad, eps 1e-5) or plain SGD + cosine warm restarts stepped every 10 epochs (reference :47-75)."""
+        cfg, kind = self.config, self.config["optimizer"]
+        if kind == "adam":
+            opt = torch.optim.AdamW(self.parameters(), lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"],
+                                    amsgrad=True, eps=1e-5)
+        elif kind == "sgd":
+            opt = torch.optim.SGD(self.parameters(), lr=cfg["learning_rate"], momentum=0.0, weight_decay=0.0,
                                   nesterov=False)
         else:
             raise ValueError(f"Unsupported optimizer: {self.config['optimizer']}.")
-        return {
-            "optimizer": opt,
-            "lr_scheduler": {
-                "scheduler": CosineAnnealingWarmRestarts(opt, self.config["warmup_steps"], T_mult=2, eta_min=1e-6),
-                "interval": "epoch",
-                "frequency": 10,
-            },
-        }
+        schedule = CosineAnnealingWarmRestarts(opt, cfg["warmup_steps"], T_mult=2, eta_min=1e-6)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": schedule, "interval": "epoch", "frequency": 10}}
+
+    def _target(self, graphs) -> torch.Tensor:
+        return graphs.assoc if self.config["dataset"] in _ASSOC_DATASETS else graphs.para
 
     def training_step(self, graphs, batch_idx):  # pylint: disable=W0613
-        if self.config["dataset"] in ("esper_assoc", "esper_assoc_only"):
-            target: torch.Tensor = graphs.assoc
-        else:
-            target: torch.Tensor = graphs.para
-        x, edge_index, edge_attr, batch = graphs.x, graphs.edge_index, graphs.edge_attr, graphs.batch
-        pred: torch.Tensor = self(x, edge_index, edge_attr, batch,
-                                  pack=_pack_of(graphs, self.model.validate_inputs, self.model.max_degree_hint))
+        target = self._target(graphs)
+        pack = _pack_of(graphs, self.model.validate_inputs, self.model.max_degree_hint)
+        pred = self(graphs.x, graphs.edge_index, graphs.edge_attr, graphs.batch, pack=pack)
         # ape = (pred - target) / target ; huber(ape, 0, delta=0.01) ; mape(pred, target) -- one kernel
         loss, both = Fn.HuberAPEFn.apply(pred, target, 0.01)
-        self.log("train_huber", loss, on_step=True, batch_size=target.shape[0], sync_dist=True)
-        self.log("train_mape", both[1], on_step=True, batch_size=target.shape[0], sync_dist=True)
+        n = target.shape[0]
+        self.log("train_huber", loss, on_step=True, batch_size=n, sync_dist=True)
+        self.log("train_mape", both[1], on_step=True, batch_size=n, sync_dist=True)
         return loss
 
     def validation_step(self, graphs, batch_idx, dataloader_idx: int = 0):  # pylint: disable=W0613
-        """Same contract as the reference (:110-153).  The density / vapour-pressure evaluation needs the CPU PC-SAFT
-        solver (``rho_batch`` / ``vp_batch`` of the reference's train/utils.py:252-300, feos), which is out of this
-        package's scope: assign callables to ``self.rho_batch`` / ``self.vp_batch`` to enable it."""
+        """Same contract as the reference (:110-153): mean absolute percentage errors of liquid density and vapour
+        pressure computed from the predicted parameters.  That evaluation needs the CPU PC-SAFT solver (``rho_batch`` /
+        ``vp_batch`` of the reference's train/utils.py:252-300, feos), which is out of this package's scope: assign
+        callables to ``self.rho_batch`` / ``self.vp_batch`` to enable it."""
         import numpy as np
 
         if self.rho_batch is None or self.vp_batch is None:
             raise RuntimeError("validation_step needs the CPU PC-SAFT oracle: set .rho_batch and .vp_batch "
                                "(reference gnnepcsaft/train/utils.py:252-300); it is out of scope here")
-        metrics_dict = {}
-        pred_para = self.model.pred_with_bounds(graphs).squeeze().detach()
-        if self.config["num_para"] == 2:
-            para_assoc = 10 ** (pred_para * torch.tensor([-1.0, 1.0], device=pred_para.device))
-            para_msigmae = graphs.para
+        predicted = self.model.pred_with_bounds(graphs).squeeze().detach()
+        signs = torch.tensor([-1.0, 1.0], device=predicted.device)  # labels hold (-log10 kappa_ab, log10 epsilon_ab)
+        if self.config["num_para"] == 2:  # the model predicts the association pair, m/sigma/epsilon come as labels
+            msigmae, assoc = graphs.para, 10 ** (predicted * signs)
         else:
-            para_assoc = 10 ** (graphs.assoc * torch.tensor([-1.0, 1.0], device=pred_para.device))
-            para_msigmae = pred_para
-        all_pred_para = (torch.hstack([para_msigmae, para_assoc, graphs.munanb, graphs.mw]).cpu().to(torch.float64)
-                         .tolist())
-        pred_rho = self.rho_batch(all_pred_para, graphs.rho)
-        pred_vp = self.vp_batch(all_pred_para, graphs.vp)
-        rho = [rho[:, -1] for rho in graphs.rho if rho.shape[0] > 0]
-        vp = [vp[:, -1] for vp in graphs.vp if vp.shape[0] > 0]
-        mape_den = [np.mean(np.abs(pred - exp) / exp).item() for pred, exp in zip(pred_rho, rho)]
-        mape_vp = [np.mean(np.abs(pred - exp) / exp).item() for pred, exp in zip(pred_vp, vp)]
-        metrics_dict.update({"mape_den": np.asarray(mape_den).mean().item(), "mape_vp": np.asarray(mape_vp).mean().item()})
-        self.log_dict(metrics_dict, on_step=False, on_epoch=True, batch_size=1, sync_dist=True)
-        return metrics_dict
+            msigmae, assoc = predicted, 10 ** (graphs.assoc * signs)
+        rows = torch.hstack([msigmae, assoc, graphs.munanb, graphs.mw]).cpu().to(torch.float64).tolist()
+
+        def mape(solver, tables) -> float:
+            measured = [t[:, -1] for t in tables if t.shape[0] > 0]
+            errs = [np.mean(np.abs(p - m) / m).item() for p, m in zip(solver(rows, tables), measured)]
+            return np.asarray(errs).mean().item()
+
+        metrics = {"mape_den": mape(self.rho_batch, graphs.rho), "mape_vp": mape(self.vp_batch, graphs.vp)}
+        self.log_dict(metrics, on_step=False, on_epoch=True, batch_size=1, sync_dist=True)
+        return metrics
 
     def test_step(self, graphs, batch_idx, dataloader_idx=0):
         return self.validation_step(graphs, batch_idx, dataloader_idx)
 
 
 class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
-    """Graph neural network to predict PCSAFT parameters (reference :159-254)."""
+    """Atom / bond encoders -> L x [dropout, conv, BatchNorm, ReLU] -> global pool -> readout MLP (reference :159-254).
+    Attribute and state-dict names follow the reference."""
 
     def __init__(self, config: dict):
         super().__init__()
-        self.convs = ModuleList()
-        self.batch_norms = ModuleList()
-        self.lower_bounds = torch.tensor([1.0, 1.9, 50.0, -1 * math.log10(0.9), math.log10(200.0)])
-        self.upper_bounds = torch.tensor([25.0, 4.5, 550.0, -1 * math.log10(0.0001), math.log10(5000.0)])
-        self.num_para = config["num_para"]
-
-        self.node_embed = gnn.AtomEncoder(config["hidden_dim"])
-        self.edge_embed = gnn.BondEncoder(config["hidden_dim"])
+        H, P = config["hidden_dim"], config["num_para"]
+        self.num_para = P
+        self.lower_bounds, self.upper_bounds = torch.tensor(_LOWER), torch.tensor(_UPPER)
+        self.node_embed, self.edge_embed = gnn.AtomEncoder(H), gnn.BondEncoder(H)
         self.dropout = Dropout(p=config["dropout"])
-        self.global_pool = get_global_pool(config)
         self.global_pool_type = config["global_pool"]
-
-        for _ in range(config["propagation_depth"]):
-            self.convs.append(get_conv(config))
-            self.batch_norms.append(BatchNorm(config["hidden_dim"]))
-
-        self.mlp = Sequential(
-            Linear(config["hidden_dim"], config["hidden_dim"] // 2),
-            BatchNorm1d(config["hidden_dim"] // 2),
-            ReLU(),
-            Linear(config["hidden_dim"] // 2, config["hidden_dim"] // 4),
-            BatchNorm1d(config["hidden_dim"] // 4),
-            ReLU(),
-            Linear(config["hidden_dim"] // 4, config["num_para"]),
-        )
+        self.global_pool = get_global_pool(config)
+        depth = config["propagation_depth"]
+        self.convs = ModuleList(get_conv(config) for _ in range(depth))
+        self.batch_norms = ModuleList(BatchNorm(H) for _ in range(depth))
+        widths = (H, H // 2, H // 4)
+        self.mlp = Sequential(Linear(widths[0], widths[1]), BatchNorm1d(widths[1]), ReLU(),
+                              Linear(widths[1], widths[2]), BatchNorm1d(widths[2]), ReLU(),
+                              Linear(widths[2], P))
         # integer inputs are range-checked on device; True = read the flag back (one sync) when a batch is packed
         self.validate_inputs = True
         # sync-free packing (HIP-graph capture): upper bound of the in-degree, e.g. len(config["deg"]) - 1; a batch that
@@ -161,91 +147,72 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
                 batch: Union[torch.Tensor, None], pack: Optional[GraphPack] = None) -> torch.Tensor:
-        """Forward pass of the model.  ``pack`` (optional) is the pre-built GraphPack of (edge_index, edge_attr, batch)."""
+        """``pack`` (optional) is the pre-built GraphPack of (edge_index, edge_attr, batch)."""
         if pack is None:
             pack = ops.pack_graph(edge_index, edge_attr, batch, x.size(0), None, validate=self.validate_inputs)
-        x = self.node_embed(x)
-        edge_attr = self.edge_embed.table()  # 60 encoded bond-feature combinations; edges index it by pack.code
-
-        for conv, batch_norm in zip(self.convs, self.batch_norms):
-            x = self.dropout(x)
-            # PNA and GINE both take edge_attr (reference :211-214); relu fused into the BatchNorm kernel
-            x = batch_norm(conv(x=x, edge_index=pack, edge_attr=edge_attr), relu=True)
-
+        h = self.node_embed(x)
+        bond_table = self.edge_embed.table()  # 60 encoded bond-feature combinations; edges index it by pack.code
+        for layer, norm in zip(self.convs, self.batch_norms):
+            # PNA and GINE both take edge_attr (reference :211-214); the ReLU is fused into the BatchNorm kernel
+            h = norm(layer(x=self.dropout(h), edge_index=pack, edge_attr=bond_table), relu=True)
         if batch is not None or pack.has_batch:
-            x = self.global_pool(x, pack)
+            h = self.global_pool(h, pack)
         else:  # batch None: reduce over all rows, keepdim (reference :220-225)
-            x = Fn.SegmentPoolFn.apply(x, pack.graph_ptr, 1, self.global_pool_type)
+            h = Fn.SegmentPoolFn.apply(h, pack.graph_ptr, 1, self.global_pool_type)
         # readout mlp (reference :186-194, :226): Linear -> BN -> ReLU -> Linear -> BN -> ReLU -> Linear
-        x = self.mlp[1](self.mlp[0](x), relu=True)
-        x = self.mlp[4](self.mlp[3](x), relu=True)
-        return self.mlp[6](x)
+        lin0, bn0, _, lin1, bn1, _, lin2 = self.mlp
+        return lin2(bn1(lin1(bn0(lin0(h), relu=True)), relu=True))
+
+    def _bounds(self, device):
+        key = (device, self.num_para)
+        if key not in self._bounds_cache:
+            cols = slice(0, 3) if self.num_para == 3 else slice(3, None)
+            self._bounds_cache[key] = (self.lower_bounds[cols].to(device=device).contiguous(),
+                                       self.upper_bounds[cols].to(device=device).contiguous())
+        return self._bounds_cache[key]
 
     def pred_with_bounds(self, data):
-        """Forward pass of the model with bounds."""
-        x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
-        if isinstance(x, torch.Tensor) and isinstance(edge_index, torch.Tensor) and isinstance(edge_attr, torch.Tensor):
-            params = self.forward(x, edge_index, edge_attr, batch, pack=_pack_of(data, self.validate_inputs))
-            key = (x.device, self.num_para)
-            if key not in self._bounds_cache:
-                upper = (self.upper_bounds[:3] if self.num_para == 3 else self.upper_bounds[3:]).to(device=x.device)
-                lower = (self.lower_bounds[:3] if self.num_para == 3 else self.lower_bounds[3:]).to(device=x.device)
-                self._bounds_cache[key] = (lower.contiguous(), upper.contiguous())
-            lower, upper = self._bounds_cache[key]
-            return ops.clip_rows(params, lower, upper)
-        raise ValueError("Invalid input data")
+        """``forward`` clipped to the physical parameter bounds (reference :229-254)."""
+        tensors = (data.x, data.edge_index, data.edge_attr)
+        if not all(isinstance(t, torch.Tensor) for t in tensors):
+            raise ValueError("Invalid input data")
+        out = self.forward(*tensors, data.batch, pack=_pack_of(data, self.validate_inputs))
+        return ops.clip_rows(out, *self._bounds(data.x.device))
 
 
 def get_conv(config: dict):
-    """Returns the convolution layer."""
-    aggregators = ["mean", "min", "max", "std"]
-    scalers = ["identity", "amplification", "attenuation"]
-    if config["conv"] == "PNA":
-        return gnn.PNAConv(
-            in_channels=config["hidden_dim"],
-            out_channels=config["hidden_dim"],
-            aggregators=aggregators,
-            scalers=scalers,
-            deg=torch.tensor(config["deg"], dtype=torch.long),
-            edge_dim=config["hidden_dim"],
-            towers=config["towers"],
-            pre_layers=config["pre_layers"],
-            post_layers=config["post_layers"],
-            divide_input=True,
-        )
-    if config["conv"] == "GINE":
-        return gnn.GINEConv(
-            nn=Sequential(
-                Linear(config["hidden_dim"], config["hidden_dim"]),
-                ReLU(),
-                Linear(config["hidden_dim"], config["hidden_dim"]),
-            ),
-            train_eps=False,
-            edge_dim=config["hidden_dim"],
-        )
-    if config["conv"] in _OUT_OF_SCOPE_CONVS:
+    """The message-passing layer named by ``config["conv"]`` with the reference's constructor arguments (:441-584)."""
+    kind, H = config["conv"], config["hidden_dim"]
+    if kind == "PNA":
+        return gnn.PNAConv(H, H, aggregators=["mean", "min", "max", "std"],
+                           scalers=["identity", "amplification", "attenuation"],
+                           deg=torch.tensor(config["deg"], dtype=torch.long), edge_dim=H, towers=config["towers"],
+                           pre_layers=config["pre_layers"], post_layers=config["post_layers"], divide_input=True)
+    if kind == "GINE":
+        return gnn.GINEConv(nn=Sequential(Linear(H, H), ReLU(), Linear(H, H)), train_eps=False, edge_dim=H)
+    if kind in _OUT_OF_SCOPE_CONVS:
         raise NotImplementedError(
             f"conv={config['conv']!r} is outside the MI355X hot-path scope (PNA, GINE); see SURVEY.md §2 row 2")
     raise ValueError(f"Unsupported convolution: {config['conv']}.")
 
 
+_POOLS = {"mean": gnn.MeanAggregation, "max": gnn.MaxAggregation, "add": gnn.SumAggregation}
+
+
 def get_global_pool(config: dict):
-    """Returns the global pooling layer."""
-    if config["global_pool"] == "mean":
-        return gnn.MeanAggregation()
-    if config["global_pool"] == "max":
-        return gnn.MaxAggregation()
-    if config["global_pool"] == "add":
-        return gnn.SumAggregation()
-    raise ValueError(f"Unsupported global pooling: {config['global_pool']}.")
+    """The readout aggregation named by ``config["global_pool"]`` (:587-595)."""
+    pool = _POOLS.get(config["global_pool"])
+    if pool is None:
+        raise ValueError(f"Unsupported global pooling: {config['global_pool']}.")
+    return pool()
 
 
 def create_model(config: dict[str, Any], deg: list[int]):
-    """Creates a model, as specified by the config."""
+    """``GNNePCSAFTL(config)`` for ``config["model"] == "gnn"``; stores ``deg`` in the config like the reference (:598-606)."""
     config["deg"] = deg
-
-    if config["model"].lower() == "gnn":
+    kind = config["model"].lower()
+    if kind == "gnn":
         return GNNePCSAFTL(config)
-    if config["model"].lower() == "habitch":
+    if kind == "habitch":
         raise NotImplementedError("HabitchNN (dense MLP baseline, reference :257-438) is out of the hot-path scope")
     raise ValueError(f"Unsupported model: {config['model']}.")
