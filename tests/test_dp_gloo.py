@@ -1,4 +1,4 @@
-"""world_size-2 ``gloo`` test (CPU) of the data-parallel logic: shard by graph, per-rank forward/backward (per-rank
+"""world_size 2 and 4 ``gloo`` tests (CPU) of the data-parallel logic: shard by graph, per-rank forward/backward (per-rank
 BatchNorm statistics and loss mean, as Lightning DDP without SyncBatchNorm), ONE exchange step = flat-buffer gradient
 all-reduce (average), ``sync_dist`` metric mean.  The oracle stands in for the compute here (there is no GPU in this
 container and no CPU fallback in the product); what is under test is ``gnnepcsaft_amd.dp`` + ``shard_by_graph``.
@@ -84,9 +84,9 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_dp_world2_gloo_matches_averaged_shard_gradients():
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_gloo_matches_averaged_shard_gradients(world):
     from gnnepcsaft_amd.data import shard_by_graph
-    world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
         outs = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(world)]
