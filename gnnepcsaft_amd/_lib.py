@@ -10,7 +10,11 @@ import torch
 
 _LIB_PATH = Path(__file__).resolve().parent / "libgnnepcsaft_hip.so"
 
+ABI_VERSION = 2
 GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
+# gnx_set_option ids (include/gnx.h)
+OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
+    OPT_STD_BWD_CENTERED = range(8)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
@@ -43,6 +47,8 @@ SIGNATURES = {
     "gnx_set_stream": (_i32, [_vp, _vp]),
     "gnx_last_error": (C.c_char_p, []),
     "gnx_abi_version": (_i32, []),
+    "gnx_set_option": (_i32, [_vp, _i32, _i32]),
+    "gnx_get_option": (_i32, [_vp, _i32, C.POINTER(_i32)]),
     "gnx_prof_begin": (_i32, [_vp, C.c_uint32]),
     "gnx_prof_read": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "gnx_prof_end": (_i32, [_vp]),
@@ -55,7 +61,9 @@ SIGNATURES = {
     "gnx_table_scatter_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "gnx_embed_sum_bwd": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(_i32), _i32, _vp, _i32, _vp, _vp, _sz]),
     "gnx_check_range": (_i32, [_vp]),
-    "gnx_gemm": (_i32, [_vp, _i32, C.POINTER(GemmSeg), _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32]),
+    "gnx_gemm_workspace_bytes": (_sz, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i32, _i64, _i32, _vp, _i32,
+                                       _i32]),
+    "gnx_gemm": (_i32, [_vp, _i32, C.POINTER(GemmSeg), _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _sz]),
     "gnx_gemm_wgrad": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "gnx_gemm_wgrad_batched": (_i32, [_vp, _i32, C.POINTER(WgradProb)]),
     "gnx_degree_max": (_i32, [_vp, _vp, _i64, C.POINTER(_i32)]),
@@ -63,7 +71,7 @@ SIGNATURES = {
     "gnx_degree_classes": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz]),
     "gnx_class_tiles": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "gnx_gemm_grouped": (_i32, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i32, _i64, _i32, _vp, _vp, _i64, _vp,
-                                _i64, _i32, _vp, _vp, _vp, _i64]),
+                                _i64, _i32, _vp, _vp, _vp, _i64, _vp, _sz]),
     "gnx_gemm_wgrad_grouped": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp,
                                       _i64]),
     "gnx_pna_weff": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
@@ -114,8 +122,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnx_abi_version() != 1:
-        raise ImportError(f"ABI version mismatch: library {lib.gnx_abi_version()} != binding 1")
+    if lib.gnx_abi_version() != ABI_VERSION:
+        raise ImportError(f"ABI version mismatch: library {lib.gnx_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 

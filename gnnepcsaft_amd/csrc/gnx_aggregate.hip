@@ -146,7 +146,7 @@ extern "C" int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const in
 template <int VEC>
 __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ dA, const float* __restrict__ m,
                                                      const float* __restrict__ A, const int* __restrict__ rowptr,
-                                                     int64_t N, int T, int F, float* __restrict__ dm) {
+                                                     int64_t N, int T, int F, float* __restrict__ dm, int centered) {
   const int H = T * F;
   const int G = H / VEC;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,11 +169,12 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
   // torch's scatter_reduce(amin/amax) backward divides by (#src ties + [self == result]) with self = the zero-filled
   // output buffer, also under include_self=False: an extremum that is exactly 0 counts one extra tie.  The reference's
   // CPU path behaves that way (verified on torch 2.10: src [0,-1,0] -> grads [1/3,0,1/3]); reproduced here.
-  float nmn[VEC], nmx[VEC];
+  float nmn[VEC], nmx[VEC], c2[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     nmn[v] = (mn[v] == 0.f) ? 1.f : 0.f;
     nmx[v] = (mx[v] == 0.f) ? 1.f : 0.f;
+    c2[v] = 0.f;
   }
   const float* mp = m + (int64_t)p0 * H + c;
   for (int p = p0; p < p1; ++p, mp += H) {
@@ -183,6 +184,8 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
     for (int v = 0; v < VEC; ++v) {
       nmn[v] += (a[v] == mn[v]) ? 1.f : 0.f;
       nmx[v] += (a[v] == mx[v]) ? 1.f : 0.f;
+      const float dv = a[v] - mean[v];
+      c2[v] = fmaf(dv, dv, c2[v]);
     }
   }
   const float cnt = (float)(p1 - p0);
@@ -192,7 +195,10 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
     k_mean[v] = gmean[v] / cnt;
     k_mn[v] = gmn[v] / nmn[v];
     k_mx[v] = gmx[v] / nmx[v];
-    k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sd[v]) : 0.f;
+    // masked or not is the forward's decision (sd, bit for bit); the divisor is the centred two-pass std, free of the
+    // cancellation error of mean(x^2) - mean(x)^2 (centered = 0: the forward's value, like the CPU path's backward)
+    const float sdiv = (centered && c2[v] > 0.f) ? sqrtf(c2[v] / cnt) : sd[v];
+    k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sdiv) : 0.f;
   }
   mp = m + (int64_t)p0 * H + c;
   float* dp = dm + (int64_t)p0 * H + c;
@@ -217,7 +223,7 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
 template <int VEC>
 __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict__ dA, const float* __restrict__ m,
                                                         const int* __restrict__ rowptr, int64_t N, int T, int F,
-                                                        float* __restrict__ dm) {
+                                                        float* __restrict__ dm, int centered) {
   const int H = T * F;
   const int G = H / VEC;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,9 +260,10 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
     }
   }
   const float cnt = (float)(p1 - p0);
-  float mean[VEC], sd[VEC], nmn[VEC], nmx[VEC];
+  float mean[VEC], sd[VEC], nmn[VEC], nmx[VEC], c2[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
+    c2[v] = 0.f;
     mean[v] = __fdiv_rn(s[v], cnt);
     float mean2 = __fdiv_rn(s2[v], cnt);
     float var = __fsub_rn(mean2, __fmul_rn(mean[v], mean[v]));
@@ -273,6 +280,8 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
     for (int v = 0; v < VEC; ++v) {
       nmn[v] += (a[v] == mn[v]) ? 1.f : 0.f;
       nmx[v] += (a[v] == mx[v]) ? 1.f : 0.f;
+      const float dv = a[v] - mean[v];
+      c2[v] = fmaf(dv, dv, c2[v]);
     }
   }
   float k_mean[VEC], k_mn[VEC], k_mx[VEC], k_sd[VEC];
@@ -281,7 +290,10 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
     k_mean[v] = gmean[v] / cnt;
     k_mn[v] = gmn[v] / nmn[v];
     k_mx[v] = gmx[v] / nmx[v];
-    k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sd[v]) : 0.f;
+    // masked or not is the forward's decision (sd, bit for bit); the divisor is the centred two-pass std, free of the
+    // cancellation error of mean(x^2) - mean(x)^2 (centered = 0: the forward's value, like the CPU path's backward)
+    const float sdiv = (centered && c2[v] > 0.f) ? sqrtf(c2[v] / cnt) : sd[v];
+    k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sdiv) : 0.f;
   }
   mp = m + (int64_t)p0 * H + c;
   float* dp = dm + (int64_t)p0 * H + c;
@@ -306,14 +318,13 @@ extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const f
   if (N == 0) return GNX_OK;
   gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD);
   {
-    const char* e = getenv("GNX_AGG_BWD_RECOMPUTE");
-    if (!(e && atoi(e) == 0)) {
+    if (h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] != 0) {
       if (F % 4 == 0)
         hipLaunchKernelGGL(k_pna_agg_bwd_rc<4>, dim3((unsigned)gnx_cdiv(N * (T * F / 4), 256)), dim3(256), 0, h->stream,
-                           dA, m, rowptr, N, (int)T, (int)F, dm);
+                           dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
       else
         hipLaunchKernelGGL(k_pna_agg_bwd_rc<1>, dim3((unsigned)gnx_cdiv(N * (int64_t)(T * F), 256)), dim3(256), 0,
-                           h->stream, dA, m, rowptr, N, (int)T, (int)F, dm);
+                           h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
       GNX_LAUNCH_CHECK();
       return GNX_OK;
     }
@@ -321,11 +332,11 @@ extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const f
   if (F % 4 == 0) {
     int64_t th = N * (T * F / 4);
     hipLaunchKernelGGL(k_pna_agg_bwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr, N,
-                       (int)T, (int)F, dm);
+                       (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
   } else {
     int64_t th = N * (T * F);
     hipLaunchKernelGGL(k_pna_agg_bwd<1>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr, N,
-                       (int)T, (int)F, dm);
+                       (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
   }
   GNX_LAUNCH_CHECK();
   return GNX_OK;

@@ -1,6 +1,7 @@
 // Handle lifecycle, error text, profiling hook, tiny elementwise helpers.
 #include "gnx_common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
@@ -35,7 +36,32 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
     delete h;
     return GNX_E_HIP;
   }
+  // option defaults, overridable once by the environment (read here, never per launch) and later by gnx_set_option
+  static const struct {
+    int id;
+    const char* env;
+    int def;
+  } opts[] = {{GNX_OPT_GEMM_SPLIT, "GNX_GEMM_SPLIT", 1},       {GNX_OPT_GEMM_WS, "GNX_GEMM_WS", 1},
+              {GNX_OPT_GEMM_VEC, "GNX_GEMM_VEC", 1},           {GNX_OPT_WGRAD_VEC, "GNX_WGRAD_VEC", 1},
+              {GNX_OPT_WGRAD_WGS, "GNX_WGRAD_WGS", 0},         {GNX_OPT_AGG_BWD_RECOMPUTE, "GNX_AGG_BWD_RECOMPUTE", 1},
+              {GNX_OPT_EMBED_BWD_MFMA, "GNX_EMBED_BWD_MFMA", 1}, {GNX_OPT_STD_BWD_CENTERED, "GNX_STD_BWD_CENTERED", 1}};
+  for (const auto& o : opts) {
+    const char* e = getenv(o.env);
+    h->opt[o.id] = e ? atoi(e) : o.def;
+  }
   *out = h;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value) {
+  GNX_CHECK_ARG(h != nullptr && opt >= 0 && opt < GNX_OPT_COUNT, "gnx_set_option: bad handle or option %d", opt);
+  h->opt[opt] = value;
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value) {
+  GNX_CHECK_ARG(h != nullptr && value != nullptr && opt >= 0 && opt < GNX_OPT_COUNT, "gnx_get_option: bad argument");
+  *value = h->opt[opt];
   return GNX_OK;
 }
 
@@ -44,7 +70,6 @@ extern "C" int32_t gnx_destroy(gnx_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   (void)hipFree(h->d_flag);
   (void)hipFree(h->d_scratch);
-  for (auto& w : h->wsplit) (void)hipFree(w.buf);
   if (h->side_fork) (void)hipEventDestroy(h->side_fork);
   if (h->side_done) (void)hipEventDestroy(h->side_done);
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -173,7 +198,8 @@ __global__ void k_clip_rows(const float* __restrict__ x, int64_t M, int P, const
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * P) return;
   int c = (int)(i % P);
-  y[i] = fminf(fmaxf(x[i], lo[c]), hi[c]);
+  const float v = x[i];
+  y[i] = (v != v) ? v : fminf(fmaxf(v, lo[c]), hi[c]);  // Tensor.clip propagates NaN (fminf/fmaxf would not)
 }
 
 extern "C" int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo,

@@ -21,13 +21,8 @@ struct gnx_handle {
   hipStream_t main_saved = nullptr;
   hipEvent_t side_fork = nullptr, side_done = nullptr;
   bool on_side = false;
-  // split-weight images of the tiled GEMM (k_split_weights -> k_gemm3): one growable buffer per stream that used it
-  struct wsplit_buf {
-    hipStream_t stream;
-    void* buf;
-    size_t bytes;
-  };
-  std::vector<wsplit_buf> wsplit;
+  // A/B switches (gnx_set_option); initialised ONCE from the GNX_* environment variables in gnx_create
+  int opt[GNX_OPT_COUNT] = {};
   // profiling: bit k of prof_mask = record an event pair around every launch group of kernel id k
   unsigned prof_mask = 0;
   std::vector<hipEvent_t> ev;

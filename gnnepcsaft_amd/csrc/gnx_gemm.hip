@@ -1072,8 +1072,7 @@ static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, i
   const int grid = g.ntiles < cus ? g.ntiles : cus;
   gnx_prof_scope prof(h, GNX_K_GEMM);
   hipError_t e;
-  const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernel (A/B switch, read per call)
-  const bool split = !(split_env && atoi(split_env) == 0);
+  const bool split = h->opt[GNX_OPT_GEMM_SPLIT] != 0;  // 0 = exact-fp32 MFMA kernel (A/B switch)
   if (split) {
     if (bt)
       e = epi == EPI_MASK    ? ws3_launch_one<true, EPI_MASK>(h, g, grid)
@@ -1099,17 +1098,15 @@ static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, i
 }
 
 // eligibility of the weights-stationary path (everything else goes to the tiled kernel)
-static bool gemm_ws_eligible(int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N, const float* mask,
-                             int32_t flags) {
+static bool gemm_ws_eligible(const gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
+                             const float* mask, int32_t flags) {
   if (nseg != 1 || M < 8192) return false;
   const gnx_gemm_seg& s = segs[0];
   if (s.rowscale != nullptr || s.k > 128 || s.k < 32 || N > 128 || N < 32) return false;
   if ((s.k % 4) != 0 || (N % 4) != 0) return false;
   if (!aligned16(s.a) || (s.lda % 4) != 0 || !aligned16(s.b) || (s.ldb % 4) != 0) return false;
   if (mask != nullptr && (flags & GNX_GEMM_ACCUMULATE)) return false;
-  const char* e = getenv("GNX_GEMM_WS");
-  if (e && atoi(e) == 0) return false;
-  return true;
+  return h->opt[GNX_OPT_GEMM_WS] != 0;
 }
 
 
@@ -1164,39 +1161,36 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
   }
 }
 
-// per-stream growable buffer for the split weight images (grows at most a few times, then steady state)
-static void* wsplit_get(gnx_handle* h, size_t bytes) {
-  gnx_handle::wsplit_buf* w = nullptr;
-  for (auto& e : h->wsplit)
-    if (e.stream == h->stream) w = &e;
-  if (w == nullptr) {
-    h->wsplit.push_back({h->stream, nullptr, 0});
-    w = &h->wsplit.back();
+// Which products take the split-operand tiled kernel (k_split_weights -> k_gemm3) and how many bytes of split weight
+// images they need.  Shared by gnx_gemm_workspace_bytes and the launch path so both always agree.
+static size_t gemm_split_bytes(const gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                               int32_t num_classes, int64_t M, int32_t N, const float* mask, int32_t flags,
+                               bool grouped) {
+  if (h == nullptr || segs == nullptr || nseg < 1 || nseg > MAX_SEGS || M < 4096 || N <= 0) return 0;
+  if (h->opt[GNX_OPT_GEMM_SPLIT] == 0 || h->opt[GNX_OPT_GEMM_VEC] == 0) return 0;
+  if (!grouped && gemm_ws_eligible(h, nseg, segs, M, N, mask, flags)) return 0;  // weights live in registers there
+  const bool bt = (flags & GNX_GEMM_B_TRANS) != 0;
+  int64_t kpad = 0;
+  int ksteps = 0;
+  for (int q = 0; q < nseg; ++q) {
+    const gnx_gemm_seg& in = segs[q];
+    const int64_t cs = cls_strides ? cls_strides[q] : 0;
+    if (in.rowscale != nullptr || in.k <= 0) return 0;
+    if (!aligned16(in.a) || (in.lda % 4) != 0 || !aligned16(in.b) || (in.ldb % 4) != 0 || (cs % 4) != 0) return 0;
+    if ((in.k % 4) != 0 || (!bt && (N % 4) != 0)) return 0;
+    ksteps += (int)gnx_cdiv((int64_t)in.k, BK);
+    kpad += gnx_cdiv((int64_t)in.k, BK) * BK;
   }
-  if (bytes > w->bytes) {
-    // kernels queued on this stream may still read the old buffer
-    if (w->buf != nullptr && hipStreamSynchronize(h->stream) != hipSuccess) {
-      gnx_set_error("gnx_gemm: stream synchronize failed while growing the split-weight buffer");
-      return nullptr;
-    }
-    (void)hipFree(w->buf);
-    w->buf = nullptr;
-    w->bytes = 0;
-    size_t cap = bytes + bytes / 2;
-    if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
-    if (hipMalloc(&w->buf, cap) != hipSuccess) {
-      gnx_set_error("gnx_gemm: cannot allocate %zu bytes for the split-weight images", cap);
-      return nullptr;
-    }
-    w->bytes = cap;
-  }
-  return w->buf;
+  if (ksteps < 2) return 0;
+  const int64_t npad = gnx_cdiv((int64_t)N, BN) * BN;
+  const int64_t D = num_classes > 0 ? num_classes : 1;
+  return (size_t)(D * 3 * npad * kpad) * sizeof(__bf16);
 }
 
 static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                            int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
                            int64_t ldc, int32_t flags, const int32_t* row_index, const int32_t* tile_info,
-                           const int32_t* ntiles, int64_t max_tiles) {
+                           const int32_t* ntiles, int64_t max_tiles, void* ws, size_t ws_bytes) {
   GNX_CHECK_ARG(h && segs && C, "gnx_gemm: NULL argument");
   GNX_CHECK_ARG(nseg >= 1 && nseg <= MAX_SEGS, "gnx_gemm: nseg=%d not in [1,%d]", nseg, MAX_SEGS);
   GNX_CHECK_ARG(M >= 0 && N > 0 && ldc >= N, "gnx_gemm: bad shape M=%lld N=%d ldc=%lld", (long long)M, N, (long long)ldc);
@@ -1211,7 +1205,7 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     GNX_CHECK_ARG(in.lda >= in.k, "gnx_gemm: segment %d: lda < k", s);
     GNX_CHECK_ARG(bt ? in.ldb >= in.k : in.ldb >= N, "gnx_gemm: segment %d: ldb too small", s);
   }
-  if (tile_info == nullptr && gemm_ws_eligible(nseg, segs, M, N, mask, flags))
+  if (tile_info == nullptr && gemm_ws_eligible(h, nseg, segs, M, N, mask, flags))
     return gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
   if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr) {
     const gnx_gemm_seg& s0 = segs[0];
@@ -1269,21 +1263,19 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   }
   const dim3 grid3(g3);
   gnx_prof_scope prof(h, GNX_K_GEMM);
-  bool vec = true;
-  {
-    const char* e = getenv("GNX_GEMM_VEC");
-    if (e && atoi(e) == 0) vec = false;
-  }
+  bool vec = h->opt[GNX_OPT_GEMM_VEC] != 0;
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
-  const char* split_env = getenv("GNX_GEMM_SPLIT");  // 0 = exact-fp32 MFMA kernels
-  int ksteps = 0;
-  for (int q = 0; q < nseg; ++q) ksteps += (int)gnx_cdiv((int64_t)g.seg[q].k, BK);
-  bool any_rs = false;
-  for (int q = 0; q < nseg; ++q) any_rs = any_rs || g.seg[q].rs != nullptr;
-  // row-scaled segments (the 4-segment post-layer-0 of hub-heavy batches) stay on the fp32-MFMA kernel
-  // small problems are launch-bound: the extra weight-split launch costs more than the faster matrix-core path saves
-  const bool split = vec && ksteps >= 2 && !any_rs && M >= 4096 && !(split_env && atoi(split_env) == 0);
+  // Split-operand path (M >= 4096, >= 2 K-tiles, no row scale): needs the caller's workspace for the split weight
+  // images (gnx_gemm_workspace_bytes).  Row-scaled segments (the 4-segment post-layer-0 of hub-heavy batches) and
+  // small, launch-bound problems stay on the fp32-MFMA kernel, and so does a call without a workspace.
+  const size_t need = gemm_split_bytes(h, nseg, segs, cls_strides, num_classes, M, N, mask, flags, tile_info != nullptr);
+  const bool split = need > 0 && ws != nullptr;
+  if (split && ws_bytes < need) {
+    gnx_set_error("gnx_gemm: workspace of %zu bytes, the split weight images need %zu", ws_bytes, need);
+    return GNX_E_WORKSPACE;
+  }
+  GNX_CHECK_ARG(!split || aligned16(ws), "gnx_gemm: workspace must be 16-byte aligned");
   if (split) {
     split_args sa;
     for (int q = 0; q < MAX_SEGS; ++q) sa.seg[q] = g.seg[q];
@@ -1298,10 +1290,7 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     sa.Npad = (int)gnx_cdiv((int64_t)N, BN) * BN;
     sa.Kpad = kp;
     sa.D = num_classes > 0 ? num_classes : 1;
-    const size_t need = (size_t)sa.D * 3 * sa.Npad * sa.Kpad * sizeof(__bf16);
-    void* buf = wsplit_get(h, need);
-    if (buf == nullptr) return GNX_E_HIP;
-    sa.out = reinterpret_cast<__bf16*>(buf);
+    sa.out = reinterpret_cast<__bf16*>(ws);
     const int64_t items = (int64_t)sa.D * sa.Npad * (sa.Kpad / 8);
     if (bt)
       hipLaunchKernelGGL(k_split_weights<true>, dim3((unsigned)gnx_cdiv(items, 256)), dim3(256), 0, h->stream, sa);
@@ -1343,18 +1332,27 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
 }
 
 extern "C" int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N,
-                            const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags) {
-  return gemm_launch(h, nseg, segs, nullptr, 1, M, N, bias, mask, ldmask, C, ldc, flags, nullptr, nullptr, nullptr, 0);
+                            const float* bias, const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags,
+                            void* ws, size_t ws_bytes) {
+  return gemm_launch(h, nseg, segs, nullptr, 1, M, N, bias, mask, ldmask, C, ldc, flags, nullptr, nullptr, nullptr, 0,
+                     ws, ws_bytes);
+}
+
+extern "C" size_t gnx_gemm_workspace_bytes(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs,
+                                           const int64_t* cls_strides, int32_t num_classes, int64_t M, int32_t N,
+                                           const float* mask, int32_t flags, int32_t grouped) {
+  return gemm_split_bytes(h, nseg, segs, cls_strides, num_classes, M, N, mask, flags, grouped != 0);
 }
 
 extern "C" int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                                     int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
                                     int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
-                                    const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles) {
+                                    const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles, void* ws,
+                                    size_t ws_bytes) {
   GNX_CHECK_ARG(cls_strides && row_index && tile_info && ntiles && max_tiles > 0, "gnx_gemm_grouped: NULL argument");
   GNX_CHECK_ARG(num_classes >= 1 && num_classes <= 4096, "gnx_gemm_grouped: num_classes=%d not in [1,4096]", num_classes);
   return gemm_launch(h, nseg, segs, cls_strides, num_classes, M, N, bias, mask, ldmask, C, ldc, flags, row_index,
-                     tile_info, ntiles, max_tiles);
+                     tile_info, ntiles, max_tiles, ws, ws_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1792,10 +1790,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3_batched(wgrad_batch_args
 }
 
 // the split-operand weight-gradient kernels take over for large row counts (GNX_GEMM_SPLIT=0: fp32 MFMA everywhere)
-static bool wgrad_split_enabled(int64_t M, bool any_rowscale) {
+static bool wgrad_split_enabled(const gnx_handle* h, int64_t M, bool any_rowscale) {
   if (any_rowscale || M < 4096) return false;
-  const char* e = getenv("GNX_GEMM_SPLIT");
-  return !(e && atoi(e) == 0);
+  return h->opt[GNX_OPT_GEMM_SPLIT] != 0;
 }
 
 static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
@@ -1821,11 +1818,7 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.vec_y = aligned16(A) && (lda % 4 == 0);
   int64_t tiles = gnx_cdiv(N, BN) * gnx_cdiv(K, BN);
   // aim for ~512 workgroups; at least 128 rows each (4 K-steps) so the atomic flush stays amortised
-  int64_t target_wgs = 512;
-  {
-    const char* e = getenv("GNX_WGRAD_WGS");
-    if (e && atoi(e) > 0) target_wgs = atoi(e);
-  }
+  const int64_t target_wgs = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? h->opt[GNX_OPT_WGRAD_WGS] : 512;
   int64_t chunks = gnx_cdiv(target_wgs, tiles);
   int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
   if (rows < 128) rows = 128;
@@ -1837,12 +1830,9 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   dim3 grid((unsigned)(chunk_info ? max_chunks : gnx_cdiv(M, rows)), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   bool vec = g.vec_x && g.vec_y && (N % 4 == 0) && (K % 4 == 0);
-  {
-    const char* e = getenv("GNX_WGRAD_VEC");
-    if (e && atoi(e) == 0) vec = false;
-  }
+  if (h->opt[GNX_OPT_WGRAD_VEC] == 0) vec = false;
   const bool offs32 = (uint64_t)M * (uint64_t)lddc < (1ull << 32) && (uint64_t)M * (uint64_t)lda < (1ull << 32);
-  if (wgrad_split_enabled(M, rowscale != nullptr) && (!chunk_info || offs32)) {
+  if (wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32)) {
     if (chunk_info)
       hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
     else
@@ -1988,7 +1978,7 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
     if (i >= nprob) continue;
     const int tn = (int)gnx_cdiv(b.p[i].N, BN), tk = (int)gnx_cdiv(b.p[i].K, BN);
     const int64_t M = b.p[i].M > 0 ? b.p[i].M : 1;
-    static const double budget = []() { const char* e = getenv("GNX_WGRAD_WGS"); return e ? atof(e) : 1024.0; }();
+    const double budget = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? (double)h->opt[GNX_OPT_WGRAD_WGS] : 1024.0;
     int64_t chunks = (int64_t)(budget * ((double)M * tn * tk / total_cost) / (tn * tk) + 0.5);
     const int64_t max_chunks = gnx_cdiv(M, 128);
     if (chunks > max_chunks) chunks = max_chunks;
@@ -2007,7 +1997,7 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   bool any_rs = false;
   for (int i = 0; i < nprob; ++i) any_rs = any_rs || probs[i].rowscale != nullptr;
-  if (wgrad_split_enabled(maxM, any_rs))
+  if (wgrad_split_enabled(h, maxM, any_rs))
     hipLaunchKernelGGL(k_gemm_wgrad3_batched, grid, dim3(256), 0, h->stream, b);
   else
     hipLaunchKernelGGL(k_gemm_wgrad_batched, grid, dim3(256), 0, h->stream, b);
@@ -2157,8 +2147,7 @@ __global__ void __launch_bounds__(256, 2) k_embed_bwd_mfma(embed_bwd_args g) {
 int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, const int32_t* offsets, int R,
                            const float* dout, int H, float* dtable) {
   if (K > EMB_MAX_K || (H % 4) != 0 || !aligned16(dout) || N < 4096) return 1;
-  const char* e = getenv("GNX_EMBED_BWD_MFMA");
-  if (e && atoi(e) == 0) return 1;
+  if (h->opt[GNX_OPT_EMBED_BWD_MFMA] == 0) return 1;
   embed_bwd_args g;
   g.idx = idx;
   for (int k = 0; k <= EMB_MAX_K; ++k) g.offs[k] = offsets[k <= K ? k : K];

@@ -182,10 +182,19 @@ class GINEConv(Module):
         self.initial_eps = eps
         self.register_buffer("eps", torch.full((1,), float(eps)))
         self.lin = Linear(edge_dim, lins[0].in_features)
+        self._eps_cache = None
+
+    def eps_value(self) -> float:
+        """Host copy of the ``eps`` buffer (a loaded checkpoint may carry a non-default value); cached by buffer
+        identity and version so the hot loop stays sync-free, like ``DegreeScalerAggregation.avg_log``."""
+        c = self._eps_cache
+        if c is None or c[0] is not self.eps or c[1] != self.eps._version:
+            self._eps_cache = c = (self.eps, self.eps._version, float(self.eps.item()))
+        return c[2]
 
     def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor) -> torch.Tensor:
         l0, l2 = self.nn[0], self.nn[2]
-        return Fn.GINEConvFn.apply(x, edge_attr, edge_index, float(self.initial_eps), self.lin.weight, self.lin.bias,
+        return Fn.GINEConvFn.apply(x, edge_attr, edge_index, self.eps_value(), self.lin.weight, self.lin.bias,
                                    l0.weight, l0.bias, l2.weight, l2.bias)
 
 

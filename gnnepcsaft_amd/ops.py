@@ -148,6 +148,15 @@ class DegreeClasses:
         return dc
 
 
+def set_option(device: torch.device, opt: int, value: int) -> int:
+    """Set an A/B switch of the device's handle (``_lib.OPT_*``; kernel selection only); returns the previous value."""
+    lib, h = _lib.load(), handle(device)
+    old = _I32(0)
+    check(lib.gnx_get_option(h, opt, C.byref(old)))
+    check(lib.gnx_set_option(h, opt, int(value)))
+    return int(old.value)
+
+
 def check_range(device: torch.device) -> None:
     """Synchronise and raise ``GnxError(GNX_E_RANGE)`` if any packer / embedding kernel saw an out-of-range integer."""
     check(_lib.load().gnx_check_range(handle(device)))
@@ -287,7 +296,11 @@ def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor]
     flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0) | \
             (_lib.GEMM_B_TRANS if b_trans else 0)
     mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
-    check(_lib.load().gnx_gemm(handle(out.device), len(segs), arr, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags))
+    lib, h = _lib.load(), handle(out.device)
+    # split weight images of the tiled split-operand kernel live in caller-owned scratch (0 bytes for most calls)
+    nbytes = lib.gnx_gemm_workspace_bytes(h, len(segs), arr, None, 1, M, N, mp, flags, 0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device) if nbytes else None
+    check(lib.gnx_gemm(h, len(segs), arr, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags, _ptr(ws), nbytes))
     return out
 
 
@@ -312,9 +325,12 @@ def gemm_grouped(segs: Sequence[GSeg], out: torch.Tensor, dc: DegreeClasses, *, 
         strides[i] = stride
     flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_B_TRANS if b_trans else 0)
     mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
-    check(_lib.load().gnx_gemm_grouped(handle(out.device), len(segs), arr, strides, dc.D, M, N, _ptr(bias), mp, ldm, cptr,
-                                       ldc, flags, dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(),
-                                       dc.max_tiles))
+    lib, h = _lib.load(), handle(out.device)
+    nbytes = lib.gnx_gemm_workspace_bytes(h, len(segs), arr, strides, dc.D, M, N, mp, flags, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device) if nbytes else None
+    check(lib.gnx_gemm_grouped(h, len(segs), arr, strides, dc.D, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags,
+                               dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(), dc.max_tiles, _ptr(ws),
+                               nbytes))
     return out
 
 
@@ -353,7 +369,10 @@ _SIDE_KEEP: dict = {}   # device index -> buffers those launches touch, kept ali
 
 def set_wgrad_side_stream(enabled: bool) -> None:
     """Run weight-gradient kernels on a second HIP stream so they overlap the input-gradient chain (the two are
-    independent inside a layer's backward).  Every autograd Function joins the side stream before it returns."""
+    independent inside a layer's backward).  A Function whose weight gradients all go into persistent in-place sinks
+    (``functional.set_grad_in_place``) defers the join to the end of the whole backward pass
+    (``join_side_stream_at_end_of_backward``); a Function that hands a freshly allocated gradient back to autograd joins
+    before it returns (``finish_backward``), because AccumulateGrad consumes that tensor on the main stream at once."""
     global _SIDE_ENABLED
     _SIDE_ENABLED = bool(enabled)
 
@@ -383,6 +402,17 @@ def join_side_stream_at_end_of_backward() -> None:
     if _SIDE_PENDING and not _JOIN_QUEUED:
         _JOIN_QUEUED = True
         torch.autograd.Variable._execution_engine.queue_callback(_join_all_side_streams)
+
+
+def finish_backward(device: torch.device, all_in_place: bool) -> None:
+    """Last call of an autograd backward that issued weight-gradient launches.  ``all_in_place``: every destination of
+    those launches is a persistent gradient buffer nobody reads before the backward pass ends -> one deferred join for
+    the whole pass.  Otherwise the Function is about to return fresh tensors that autograd accumulates on the main
+    stream immediately -> the main stream waits for the side stream now."""
+    if all_in_place:
+        join_side_stream_at_end_of_backward()
+    else:
+        join_side_stream(device)
 
 
 _WGRAD_QUEUE: List[tuple] = []
@@ -440,7 +470,7 @@ def flush_wgrads() -> None:
             arr[k].dC, arr[k].lddc, arr[k].A, arr[k].lda = xp, ldx, ap, lda
             arr[k].rowscale, arr[k].dW, arr[k].lddw, arr[k].dbias = _ptr(rs), wp, ldw, _ptr(db)
             arr[k].M, arr[k].N, arr[k].K = M, N, K
-            keep += [dC, A, rs]
+            keep += [dC, A, rs, dW, db]
         ref = chunk[0][0]
         n = len(chunk)
         _run_on_side(ref, keep, lambda arr=arr, n=n, ref=ref: check(
@@ -478,7 +508,7 @@ def gemm_wgrad(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, *, rowscale:
     """dW[N,K] += dC[M,N]^T @ (rowscale * A[M,K]);  dbias[N] += column sums of dC."""
     if dC.size(0) == 0:
         return
-    _run_on_side(dC, (dC, A, rowscale), lambda: _gemm_wgrad_launch(dC, A, dW, rowscale, dbias))
+    _run_on_side(dC, (dC, A, rowscale, dW, dbias), lambda: _gemm_wgrad_launch(dC, A, dW, rowscale, dbias))
 
 
 def pna_post0_wgrad_classes(g: torch.Tensor, A: torch.Tensor, dc: "DegreeClasses", F: int, avg_deg_log: float,
@@ -492,7 +522,7 @@ def pna_post0_wgrad_classes(g: torch.Tensor, A: torch.Tensor, dc: "DegreeClasses
         gemm_wgrad_grouped(g, A, dWeff, dc)
         pna_weff_bwd(dWeff, F, dc.D, avg_deg_log, dW)
 
-    _run_on_side(g, (g, A, dWeff), run)
+    _run_on_side(g, (g, A, dWeff, dW), run)
 
 
 def _gemm_wgrad_launch(dC, A, dW, rowscale, dbias) -> None:

@@ -10,11 +10,14 @@
  *  - every function returns int32 status: 0 = ok, <0 = error (GNX_E_*); text via gnx_last_error() (thread-local).
  *  - the library never allocates or frees tensor memory: all buffers (inputs, outputs, workspaces) are caller-owned
  *    DEVICE pointers (hipMalloc / torch tensors' data_ptr()); workspace sizes are queried with *_workspace_bytes.
+ *    (The handle itself owns 4.25 KiB of device memory for the sticky range flag, allocated in gnx_create.)
  *  - all launches go on the handle's stream (gnx_set_stream; default = the NULL stream) and are asynchronous.
  *    Only gnx_check_range (integer input validation read-back) and gnx_prof_end synchronise that stream.
  *  - all float tensors are fp32 row-major; "ld" = leading dimension in elements.  Index tensors handed over by the
  *    caller in the reference's layout are int64; everything the library produces is int32.
- *  - no hidden global state except the opaque gnx_handle (device id, stream, profiling events).
+ *  - no hidden global state except the opaque gnx_handle (device id, stream, options, profiling events).  The GNX_*
+ *    environment variables are read ONCE, in gnx_create, as initial option values; no entry point reads the
+ *    environment afterwards (gnx_set_option changes an option at run time).
  */
 #ifndef GNX_H_
 #define GNX_H_
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 1
+#define GNX_ABI_VERSION 2
 
 enum {
   GNX_OK = 0,
@@ -44,6 +47,22 @@ int32_t gnx_destroy(gnx_handle* h);
 int32_t gnx_set_stream(gnx_handle* h, void* hip_stream);
 const char* gnx_last_error(void);
 int32_t gnx_abi_version(void);
+
+/* A/B switches of the handle (kernel selection only; every setting computes the same function).  Initial value = the
+ * environment variable of the same name with the GNX_ prefix (e.g. GNX_GEMM_SPLIT=0), read once in gnx_create. */
+enum {
+  GNX_OPT_GEMM_SPLIT = 0,        /* 1: products with >= 4096 rows as three-bf16-piece split products; 0: fp32 MFMA */
+  GNX_OPT_GEMM_WS = 1,           /* 1: weights-stationary kernel for one segment with K, N <= 128, M >= 8192 */
+  GNX_OPT_GEMM_VEC = 2,          /* 0: element-wise loaders everywhere (debug) */
+  GNX_OPT_WGRAD_VEC = 3,         /* 0: element-wise weight-gradient loaders (debug) */
+  GNX_OPT_WGRAD_WGS = 4,         /* > 0: target workgroup count of the weight-gradient kernels */
+  GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
+  GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 4096 */
+  GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
+  GNX_OPT_COUNT = 8
+};
+int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
+int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
 
 /* ---- profiling hook (bench.py's live per-kernel timing; HIP events on the handle's stream) ------------------- */
 /* kernel ids */
@@ -110,7 +129,10 @@ int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t N, int32_t 
                           int32_t R, const float* dout, int32_t H, float* dtable, void* ws, size_t ws_bytes);
 int32_t gnx_check_range(gnx_handle* h); /* sync; GNX_E_RANGE if any lazy check tripped since the last call */
 
-/* ---- dense contractions: fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 ------------------------------------ */
+/* ---- dense contractions on the matrix cores ------------------------------------------------------------------
+ * Arithmetic: products with >= 4096 rows evaluate every fp32 operand as an exact sum of three bf16 pieces and the
+ * product as six v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-faithful: dropped terms <= 2^-25 |a||b|;
+ * DESIGN.md §2); smaller products, row-scaled segments and GNX_OPT_GEMM_SPLIT = 0 use v_mfma_f32_32x32x2_f32. */
 /* One A-operand segment of a K-concatenated product.  The product is
  *     C[m,n] (+)= act( sum_s  sum_{k<K_s} (rs_s[m] * A_s[m,k]) * B_s(k,n)  + bias[n] )        m<M, n<N
  *   b_trans = 1 ("NT", forward Linear):   B_s(k,n) = B_s[n*ldb + k]   (weight [out,in] row-major, PyG/torch layout)
@@ -133,9 +155,16 @@ enum {
   GNX_GEMM_ACCUMULATE = 2, /* C += (applied before relu; relu+accumulate is rejected) */
   GNX_GEMM_B_TRANS = 4     /* NT */
 };
-/* mask (optional, may be NULL): multiply the result by (mask[m*ldmask+n] > 0) — ReLU backward fused in dgrad. */
+/* mask (optional, may be NULL): multiply the result by (mask[m*ldmask+n] > 0) — ReLU backward fused in dgrad.
+ * ws / ws_bytes: caller-owned device scratch for the split weight images of the tiled split-operand kernel, size from
+ * gnx_gemm_workspace_bytes with the same arguments (0 = this call needs none).  ws == NULL is allowed: the product
+ * then runs on the fp32-MFMA kernel.  A non-NULL workspace that is too small returns GNX_E_WORKSPACE.  The scratch is
+ * free for reuse as soon as the launches of this call have run (stream order). */
+size_t gnx_gemm_workspace_bytes(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                                int32_t num_classes, int64_t M, int32_t N, const float* mask, int32_t flags,
+                                int32_t grouped);
 int32_t gnx_gemm(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, int64_t M, int32_t N, const float* bias,
-                 const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags);
+                 const float* mask, int64_t ldmask, float* C, int64_t ldc, int32_t flags, void* ws, size_t ws_bytes);
 /* weight gradient ("TN"): dW[n, k] += sum_m dC[m,n] * (rs[m] * A[m,k]),  n<N, k<K.  Split over M across workgroups,
  * fp32 atomics into dW (caller zeroes or accumulates).  dbias (optional) += column sums of dC. */
 int32_t gnx_gemm_wgrad(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda,
@@ -179,7 +208,7 @@ int32_t gnx_class_tiles(gnx_handle* h, const int32_t* cls_ptr, int32_t D, int32_
 int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                          int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
                          int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
-                         const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles);
+                         const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles, void* ws, size_t ws_bytes);
 /* per-class weight gradient: dW_cls[c] (stride dw_cls_stride) += sum over the rows of class c of dC[row]^T A[row]. */
 int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M,
                                int32_t N, int32_t K, float* dW_cls, int64_t lddw, int64_t dw_cls_stride,
@@ -219,7 +248,11 @@ int32_t gnx_key_segment_sum(gnx_handle* h, const float* g, const int32_t* pos, c
 int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int32_t T, int32_t F,
                               float* A);
 /* dm[E,T*F] from dA[N,T,4F]; min/max gradients split evenly over ties (scatter_reduce amin/amax backward);
- * std gradient 0 where the forward masked. */
+ * std gradient 0 where the forward masked (the mask decision is the forward's, bit for bit).  Where it is not masked
+ * the gradient is dstd (m - mean) / (n std): with GNX_OPT_STD_BWD_CENTERED (default) `std` is re-evaluated as
+ * sqrt(sum (m - mean)^2 / n), which is accurate to fp32 rounding, instead of the forward's mean(x^2) - mean(x)^2 whose
+ * cancellation error (~ eps mean(x^2) / (2 var) relative, up to 3e-5 just above the mask) the CPU path carries into
+ * its gradient; 0 = divide by the forward's value like the CPU path does. */
 int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A, const int32_t* rowptr,
                               int64_t N, int32_t T, int32_t F, float* dm);
 
@@ -279,7 +312,7 @@ int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
 int32_t gnx_side_begin(gnx_handle* h);
 int32_t gnx_side_end(gnx_handle* h);
 int32_t gnx_side_join(gnx_handle* h);
-/* y[m,:] = clip(x[m,:], lo[:], hi[:])   (pred_with_bounds, ref: train/models.py:246-253) */
+/* y[m,:] = clip(x[m,:], lo[:], hi[:]), NaN propagates like Tensor.clip  (pred_with_bounds, ref: train/models.py:246-253) */
 int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo, const float* hi, float* y);
 
 #ifdef __cplusplus

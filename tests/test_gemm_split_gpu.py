@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from gnnepcsaft_amd import _lib
 from tests.parity_util import rel_err
 from tests.test_ops_gpu import _graph, _pack
 
@@ -113,13 +114,13 @@ def test_split_and_exact_kernels_agree(gpu_device):
     ref = torch.cat([x, A], 1).double() @ W.double().T
     outs = {}
     for mode in ("1", "0"):
-        os.environ["GNX_GEMM_SPLIT"] = mode
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
         try:
             out = torch.empty(M, F, device=gpu_device)
             ops.gemm([(xd, None, Wd[:, :F]), (Ad, None, Wd[:, F:])], out)
             outs[mode] = out.double().cpu()
         finally:
-            os.environ.pop("GNX_GEMM_SPLIT", None)
+            ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, 1)
     assert rel_err(outs["1"], ref) <= TOL and rel_err(outs["0"], ref) <= TOL
     assert rel_err(outs["1"], outs["0"]) <= 2e-6
     assert rel_err(outs["1"], ref) <= rel_err(outs["0"], ref) * 1.5 + 1e-8

@@ -5,6 +5,7 @@ import os
 import pytest
 import torch
 
+from gnnepcsaft_amd import _lib
 from tests.parity_util import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -90,13 +91,13 @@ def test_split_operand_product_is_fp32_faithful(gpu_device, b_trans, scale):
     norm = a.double().abs() @ wm.abs()
     errs = {}
     for mode in ("1", "0"):
-        os.environ["GNX_GEMM_SPLIT"] = mode
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
         try:
             out = torch.empty(M, N, device=gpu_device)
             ops.gemm([(ad, None, wd)], out, b_trans=b_trans)
             errs[mode] = float(((out.double().cpu() - ref).abs() / norm).max())
         finally:
-            os.environ.pop("GNX_GEMM_SPLIT", None)
+            ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, 1)
     eps32 = 2.0 ** -24
     # measured: exact-fp32 MFMA (sequential k chain) ~10 ulp max / 0.7 rms; split product ~4 ulp max / 0.27 rms
     assert errs["0"] <= 24 * eps32

@@ -1,13 +1,14 @@
 """GPU parity of the whole hot path (embed -> L x [conv -> BN -> ReLU] -> pool -> readout -> APE-Huber -> backward)
 against the CPU oracle on the same seeded inputs and identical weights (state dicts are interchangeable).
 
-Tolerances (see tests/parity_util.py for why):
-  * loss: 1e-5 relative against the CPU fp32 oracle, every case (BASELINE.json's north-star tolerance);
-  * predictions: 1e-5 norm-wise relative against the CPU fp32 oracle where the reference algorithm is well conditioned
-    in fp32 (all GINE models; PNA models whose std aggregator stays off its var<=1e-5 mask edge);
-  * every case, predictions + loss + gradients: the HIP path is no further from the oracle evaluated in fp64 than
-    3x the CPU fp32 oracle's own distance (+1e-5) — PyG's StdAggregation (mean(x^2)-mean(x)^2, hard mask) makes the
-    reference's fp32 result itself reproducible only to 1e-4..1e-3 at random initialisation.
+Every case of tests/model_cases.py (BASELINE configs[0], [1], [2], [4] shapes among them; the full-depth cfg-2 / cfg-3
+models on 1024 graphs and a cfg-5-shaped H=512 / T=4 / skewed batch run every large-batch kernel) is held to:
+  * loss: 1e-5 relative against the CPU fp32 oracle (BASELINE.json's north-star tolerance);
+  * predictions, every per-layer intermediate and its gradient, the whole gradient (L2) and the worst parameter:
+    distance to the oracle evaluated in fp64 <= max(1e-5, 1.5 x the reference's own fp32 reproducibility envelope on
+    that case) -- tests/parity_util.py explains why that envelope, and not 1e-5, is what a whole model can be held to;
+  * GINE models (no std / min / max aggregation) additionally: predictions within 1e-5 of the CPU fp32 oracle.
+Single layers are held to 1e-5 outright in tests/test_conv_gpu.py.
 """
 import copy
 
@@ -16,7 +17,8 @@ import pytest
 import torch
 
 from oracle import pyg_restatement as O
-from tests.parity_util import assert_as_close_as_cpu_fp32, compare_with_oracle, make_models, rel_err
+from tests.model_cases import MODEL_CASES, build_case
+from tests.parity_util import assert_within_reference_envelope, compare_with_oracle, make_models, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -28,117 +30,56 @@ def _cfg(**kw):
     return cfg
 
 
-CASES = {
-    "pna_small": dict(hidden_dim=64, propagation_depth=2),
-    "pna_cfg1_shape": dict(hidden_dim=256, propagation_depth=6),  # BASELINE configs[0]: batch 32, H=256
-    "pna_towers4": dict(hidden_dim=128, towers=4, propagation_depth=2),
-    "pna_pre1_post1": dict(hidden_dim=32, pre_layers=1, post_layers=1, propagation_depth=2),
-    "pna_pre3_post2_mean": dict(hidden_dim=48, pre_layers=3, post_layers=2, propagation_depth=2, global_pool="mean"),
-    "pna_max_pool_assoc": dict(hidden_dim=32, propagation_depth=2, global_pool="max", num_para=2),
-    "gine_small": dict(conv="GINE", hidden_dim=64, propagation_depth=3),
-    "gine_h256": dict(conv="GINE", hidden_dim=256, propagation_depth=6),
-}
-
-
-WELL_CONDITIONED = {"gine_small", "gine_h256", "pna_pre1_post1", "pna_pre3_post2_mean"}
-
-
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(MODEL_CASES))
 def test_model_fwd_bwd_parity(gpu_device, name):
-    from gnnepcsaft_amd.data import synthetic_batch
-    cfg = _cfg(**CASES[name])
-    batch = synthetic_batch(32, 1)
-    res = compare_with_oracle(cfg, batch, device="cuda:0", target="assoc" if cfg["num_para"] == 2 else "para")
-    print(name, res)
+    cfg, batch, target = build_case(name)
+    res = compare_with_oracle(cfg, batch, device="cuda:0", target=target)
+    print(name, {k: v for k, v in res.items() if not isinstance(v, (dict, list))})
     assert res["loss_rel"] <= 1e-5, res
-    assert_as_close_as_cpu_fp32(res)
-    if name in WELL_CONDITIONED:
-        assert res["pred_rel"] <= 1e-5, res
-        assert res["grad_rel_l2"] <= 1e-3, res
-
-
-def test_model_skewed_graphs_and_ties(gpu_device):
-    """cfg-5-like skewed sizes (5..80 atoms, hubs) and molecule-like features that produce exactly tied messages."""
-    from gnnepcsaft_amd.data import synthetic_batch
-    cfg = _cfg(hidden_dim=64, towers=2, propagation_depth=3)
-    res = compare_with_oracle(cfg, synthetic_batch(64, 5), device="cuda:0")
-    print("skewed", res)
-    assert res["loss_rel"] <= 1e-5, res
-    assert_as_close_as_cpu_fp32(res)
-    res = compare_with_oracle(cfg, synthetic_batch(64, 2, molecule_like=True), device="cuda:0")
-    print("ties", res)
-    assert res["loss_rel"] <= 1e-5, res
-    assert_as_close_as_cpu_fp32(res)
-
-
-def test_model_edge_cases_single_atoms_and_empty_graphs(gpu_device):
-    """Single-heavy-atom molecules emit edge_index[2,0] (ogb_utils.py:137-139): degree-0 nodes, edgeless graphs."""
-    from gnnepcsaft_amd.data import Batch, Data, synthetic_batch
-    base = synthetic_batch(6, 2).to_data_list()
-    lone = Data(x=torch.tensor([[5, 0, 4, 5, 3, 0, 2, 0, 0]]), edge_index=torch.empty(2, 0, dtype=torch.long),
-                edge_attr=torch.empty(0, 3, dtype=torch.long), para=torch.tensor([[2.0, 3.0, 200.0]]),
-                assoc=torch.tensor([[1.0, 3.0]]))
-    batch = Batch.from_data_list([lone, base[0], lone, base[1], base[2], lone])
-    for conv in ("PNA", "GINE"):
-        cfg = _cfg(conv=conv, hidden_dim=32, propagation_depth=2)
-        res = compare_with_oracle(cfg, batch, device="cuda:0")
-        print(conv, res)
-        assert res["loss_rel"] <= 1e-5, res
-        assert_as_close_as_cpu_fp32(res)
-
-
-def test_model_cfg2_shape_vs_fp64(gpu_device):
-    """BASELINE configs[1] model (PNA H=128, L=6) on 256 graphs: three-way comparison with the fp64 oracle."""
-    from gnnepcsaft_amd.data import synthetic_batch
-    cfg = _cfg(hidden_dim=128, propagation_depth=6)
-    res = compare_with_oracle(cfg, synthetic_batch(256, 2), device="cuda:0")
-    print("cfg2-shape", res)
-    assert res["loss_rel"] <= 1e-5, res
-    assert_as_close_as_cpu_fp32(res)
-
-
-@pytest.mark.parametrize("conv,hidden,graphs", [("PNA", 128, 640), ("GINE", 256, 512)])
-def test_model_at_large_batch_kernels(gpu_device, conv, hidden, graphs):
-    """Batches of >= 8192 atoms select the large-batch kernels (split-operand products, degree classes, one-hot MFMA
-    embedding gradient, recomputing scatter backward) that the 32-graph cases never reach: same three-way criterion
-    against the fp64 oracle, two layers to keep the CPU oracle at a few seconds."""
-    from gnnepcsaft_amd.data import synthetic_batch
-    cfg = _cfg(conv=conv, hidden_dim=hidden, propagation_depth=2)
-    res = compare_with_oracle(cfg, synthetic_batch(graphs, 2 if conv == "PNA" else 3), device="cuda:0")
-    print("large", conv, res)
-    assert res["loss_rel"] <= 1e-5, res
-    assert_as_close_as_cpu_fp32(res)
-    if conv == "GINE":
+    assert_within_reference_envelope(res, name)
+    if cfg["conv"] == "GINE":
         assert res["pred_rel"] <= 1e-5, res
 
 
 @pytest.mark.parametrize("name", ["pna_h32_l2_t2", "gine_h32_l2"])
-def test_hip_path_against_committed_golden_vectors(gpu_device, name):
-    """HIP forward/backward vs the committed fp64 golden vectors (tests/golden/*.npz; generating script alongside).
-    Nothing under /root/reference is read.  Tolerances = what the reference's own fp32 CPU path achieves against the
-    same vectors (tests/test_host_cpu.py::test_oracle_reproduces_golden) — loss 1e-5, predictions 2e-3 norm-wise."""
-    import os
+def test_hip_path_against_committed_golden_fixtures(gpu_device, name):
+    """HIP forward/backward on a committed fixture (tests/golden/*.npz: inputs, weights, fp64 per-layer intermediates,
+    their gradients, predictions, loss, every parameter gradient, BatchNorm statistics after the step; generating
+    script alongside).  Nothing is regenerated from seeds and nothing under /root/reference is read.  Every array is
+    compared layer by layer, so a failure names the first layer that left the fixture; bound per metric =
+    max(1e-5, 1.5 x the reference's own fp32 reproducibility envelope stored in the fixture)."""
     from gnnepcsaft_amd import functional as Fn
     from gnnepcsaft_amd.train.models import GNNePCSAFT
-    from tests.golden.make_golden import CASES, build
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
-    cfg, batch, omodel = build(CASES[name])
+    from tests.golden.make_golden import load_fixture
+    from tests.parity_util import capture_intermediates, grad_errors
+    cfg, batch, state, gold = load_fixture(name)
     native = GNNePCSAFT(cfg)
-    native.load_state_dict(omodel.state_dict(), strict=True)
+    native.load_state_dict(state, strict=True)
     native.train().to("cuda:0")
     b = batch.to("cuda:0")
-    pred = native(b.x, b.edge_index, b.edge_attr, b.batch)
+    cap = capture_intermediates(native)
+    with cap as inter:
+        pred = native(b.x, b.edge_index, b.edge_attr, b.batch)
     loss, _ = Fn.HuberAPEFn.apply(pred, b.para, 0.01)
     loss.backward()
-    assert abs(float(loss) - float(gold["loss"])) <= 1e-5 * abs(float(gold["loss"]))
-    assert rel_err(pred, torch.from_numpy(gold["pred"])) <= 2e-3
-    params = dict(native.named_parameters())
-    for k in gold.files:
-        if k.startswith("grad."):
-            g = params[k[5:]].grad
-            ref = torch.from_numpy(gold[k])
-            assert rel_err(g, ref, floor=1e-2 * float(ref.abs().max()) + 1e-12) <= 5e-2, k
-    assert rel_err(native.batch_norms[0].module.running_mean, torch.from_numpy(gold["running_mean.0"])) <= 1e-4
+    torch.cuda.synchronize()
+    bound = {k[4:]: max(1e-5, 1.5 * float(gold[k])) for k in gold.files if k.startswith("env.")}
+    assert abs(float(loss) - float(gold["loss"])) <= bound["loss"] * abs(float(gold["loss"]))
+    for k, v in inter.items():  # forward, in layer order: embed, conv0, act0, conv1, ...
+        assert rel_err(v, torch.from_numpy(gold["inter." + k]).double()) <= bound["inter"], ("forward", k)
+    assert rel_err(pred, torch.from_numpy(gold["pred"])) <= bound["pred"]
+    for k, v in reversed(list(cap.grads().items())):  # backward, in the order the gradient flows: d_pool, ...
+        if "dinter." + k not in gold.files:  # d_act{l}: the oracle has no fused BatchNorm+ReLU output to differentiate
+            continue
+        assert rel_err(v, torch.from_numpy(gold["dinter." + k]).double()) <= bound["dinter"], ("backward", k)
+    g = {n: p.grad.detach().double().cpu() for n, p in native.named_parameters()}
+    ref = {n: torch.from_numpy(gold["grad." + n]).double() for n in g}
+    ge = grad_errors(g, ref)
+    assert ge["l2"] <= bound["grad_l2"], ge
+    assert ge["max"] <= bound["grad_max"], ge
+    for n, buf in native.named_buffers():
+        if "after." + n in gold.files:
+            assert rel_err(buf, torch.from_numpy(gold["after." + n]).double()) <= bound["inter"], n
 
 
 @pytest.mark.parametrize("conv", ["PNA", "GINE"])
@@ -254,3 +195,36 @@ def test_degree_class_path_matches_segment_path(gpu_device):
     assert rel_err(outs[0][0], outs[1][0]) <= 1e-5
     num = float((outs[0][1] - outs[1][1]).norm())
     assert num <= 2e-3 * float(outs[1][1].norm()), num
+
+
+@pytest.mark.parametrize("conv", ["PNA", "GINE"])
+def test_side_stream_without_in_place_sinks_equals_inline(gpu_device, conv):
+    """weight-gradient kernels on the side stream while the Functions hand FRESH gradient tensors back to
+    autograd (grad_in_place off; a FlatGradAllReduce is attached, so AccumulateGrad adds into its views on the main
+    stream).  Each Function must join before returning, or the accumulation races the side kernels."""
+    from gnnepcsaft_amd import dp, functional as Fn, ops
+    from gnnepcsaft_amd.data import calc_deg, synthetic_batch
+    from gnnepcsaft_amd.train.models import create_model
+    cfg = _cfg(conv=conv, hidden_dim=128, propagation_depth=3)
+    batch = synthetic_batch(512, 2)  # 10 240 atoms: the large-batch weight-gradient kernels
+    deg = calc_deg(batch)
+    b = batch.to("cuda:0")
+    torch.manual_seed(0)
+    m1 = create_model(copy.deepcopy(cfg), deg).to("cuda:0")
+    m2 = create_model(copy.deepcopy(cfg), deg).to("cuda:0")
+    m2.load_state_dict(m1.state_dict())
+    m1.training_step(b, 0).backward()  # inline reference
+    ref = torch.cat([p.grad.reshape(-1) for p in m1.parameters()])
+    flat = dp.FlatGradAllReduce(m2)
+    Fn.set_grad_in_place(False)
+    try:
+        ops.set_wgrad_side_stream(True)
+        for _ in range(3):
+            flat.zero_grad()
+            b._gnx_pack = None
+            m2.training_step(b, 0).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_wgrad_side_stream(False)
+    assert not ops._SIDE_PENDING and not ops._SIDE_KEEP
+    assert rel_err(flat.flat, ref) <= 1e-5

@@ -1,7 +1,7 @@
 """Timing of the tiled multi-segment GEMM on the three PNA shapes that use it (cfg-2 sizes)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gnnepcsaft_amd import ops
+from gnnepcsaft_amd import _lib, ops
 dev = torch.device("cuda:0")
 M, F = 81920, 128
 x = torch.randn(M, F, device=dev); A = torch.randn(M, 4 * F, device=dev)
@@ -16,7 +16,7 @@ cases = {
 }
 for name, (fn, byts, flops) in cases.items():
     for mode in (os.environ.get("DIAG_MODES", "1,0").split(",")):
-        os.environ["GNX_GEMM_SPLIT"] = mode
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
         for _ in range(5): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,14 +1,14 @@
 """A/B timing of the weights-stationary GEMM: split-bf16 (default) vs exact fp32 MFMA (GNX_GEMM_SPLIT=0)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gnnepcsaft_amd import ops
+from gnnepcsaft_amd import _lib, ops
 dev = torch.device("cuda:0")
 for M in (81920, 163840):
     a = torch.randn(M, 128, device=dev); w = torch.randn(128, 128, device=dev); out = torch.empty(M, 128, device=dev)
     mask = torch.randn(M, 128, device=dev)
     for bt, mk in ((True, None), (False, None), (True, mask), (False, mask)):
         for mode in ("1", "0"):
-            os.environ["GNX_GEMM_SPLIT"] = mode
+            ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
             for _ in range(5): ops.gemm([(a, None, w)], out, b_trans=bt, mask=mk)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,7 +1,7 @@
 """A/B timing of the weight-gradient kernels: split-bf16 (default) vs fp32 MFMA (GNX_GEMM_SPLIT=0)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gnnepcsaft_amd import ops
+from gnnepcsaft_amd import _lib, ops
 dev = torch.device("cuda:0")
 ops.set_wgrad_side_stream(False)
 for M, N, K, nprob in ((81920, 128, 128, 1), (81920, 128, 128, 8), (163840, 128, 128, 1), (81920, 128, 512, 1)):
@@ -13,7 +13,7 @@ for M, N, K, nprob in ((81920, 128, 128, 1), (81920, 128, 128, 8), (163840, 128,
             ops.queue_wgrad(g[i], x[i], dw[i])
         ops.flush_wgrads()
     for mode in ("1", "0"):
-        os.environ["GNX_GEMM_SPLIT"] = mode
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
