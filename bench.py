@@ -9,6 +9,12 @@ Workload at N=1: BASELINE.json configs[1] — PNA, hidden=128, L=6, pre=2, post=
 20 atoms / 40 directed bonds.  N>1: the same per-GPU batch on every rank (weak scaling), graphs independent per rank,
 one exchange step (flat-buffer gradient all-reduce over RCCL).
 
+Launch: ``python bench.py --gpus N`` starts N rank processes itself (one per GPU, RCCL = torch.distributed "nccl") when
+it was not started under torchrun (no WORLD_SIZE in the environment); under
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it is one of the ranks.  Either way N must
+equal the number of ranks, N devices must be visible, and ``n_gpus`` in the JSON is the number of ranks that joined the
+timing barrier.  ``--dry-run`` rehearses the launch / barrier / exchange protocol on the CPU (gloo, no kernels).
+
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
   roofline     — the scatter-aggregate kernel (gnx_pna_aggregate_fwd): algorithmic bytes per launch / its average
                  duration, timed live with HIP events on the launch stream during the timed steps, vs 8 TB/s HBM;
@@ -46,6 +52,97 @@ def ref_flops_per_graph(cfg, n=20, e=40):
     return L * (e * f_edge + n * f_node) + f_read
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args) -> int:
+    """Parent of a ``--gpus N`` run that was not started under torchrun: starts N fresh rank processes (this process
+    never touches the GPU: ``torch.cuda.device_count()`` does not initialise it, and nothing is exec'ed from a process
+    that did) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, forwards rank 0's stdout (the JSON line), and
+    returns non-zero if any rank fails."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} HIP device(s) visible", file=sys.stderr, flush=True)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in pending.values():
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """The launch / barrier / timing / exchange protocol without a GPU: gloo ranks, a flat buffer of cfg-2's gradient
+    size standing in for the step.  Checks that N ranks really joined (tests/test_host_cpu.py runs it at N = 2)."""
+    import torch.distributed as dist
+    if world > 1 or args.force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.full((2204931,), float(rank + 1))
+    joined = torch.ones(1)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(joined, op=dist.ReduceOp.SUM)
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "molecular graphs/sec (fwd+bwd)", "value": 0.0, "unit": "graphs/s",
+                          "n_gpus": int(joined.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": float(elapsed) / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": "dry run: launch + barrier + gradient exchange protocol only (gloo, CPU)",
+                                     "parallelism": f"dp{world}"}, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,14 +157,37 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into a HIP graph and replay it (measured: no gain over eager launches here — "
                          "dependent-kernel boundaries cost the same either way and the CPU already runs ahead)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse launch + barrier + exchange on the CPU (gloo); no kernels, value 0")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the RCCL exchange path even with one rank (rehearsal on a one-GPU box)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one all-reduce after backward instead of per-layer slices started during backward")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # this process stays GPU-free; the ranks are fresh children
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+              f"(python bench.py --gpus N, or torchrun --nproc-per-node N bench.py --gpus N)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if args.dry_run:
+        dry_run(args, world, rank)
+        return
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if torch.cuda.device_count() <= local_rank:
+            print(f"[bench] rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible",
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -96,7 +216,7 @@ def main():
     model.train()
     model.model.validate_inputs = False  # range flag is read back once per step below (no sync inside the step)
     dp.broadcast_parameters(model)
-    flat = dp.FlatGradAllReduce(model)
+    flat = dp.FlatGradAllReduce(model, force_collective=args.force_dp)
     Fn.set_grad_in_place(True)  # weight-gradient kernels accumulate straight into the flat all-reduce buffer
     ops.set_wgrad_side_stream(not args.no_side_stream)  # wgrad kernels overlap the dgrad chain on a second stream
     Fn.set_degree_classes(not args.no_degree_classes)
@@ -115,9 +235,15 @@ def main():
         loss.backward()
         return loss
 
+    # gradient exchange: every conv layer's slice of the flat buffer is handed to RCCL as soon as that layer's
+    # weight-gradient launches are issued (overlaps the rest of backward); the remainder follows after backward;
+    # finish() waits stream-wise and turns the sum into the average with one gnx_scale launch
+    flat.enable_overlap(not args.no_overlap and not args.graph)
+
     def eager_step():
         loss = step_body()
-        flat.all_reduce()
+        flat.all_reduce(async_op=True)
+        flat.finish()
         return loss
 
     for _ in range(args.warmup):
@@ -178,16 +304,21 @@ def main():
     n_g, ms_g = ops.prof_read(dev, _lib.K_GEMM)
     n_w, ms_w = ops.prof_read(dev, _lib.K_GEMM_WGRAD)
     ops.prof_end(dev)
+    joined = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        j = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(j, op=dist.ReduceOp.SUM)
+        joined = int(j.item())  # ranks that took part in the timed region
     loss_val = float(loss.detach())
     if rank == 0:
         print(f"[bench] gpu: {args.steps} steps in {elapsed:.3f}s, loss {loss_val:.6f}", file=sys.stderr, flush=True)
     assert loss_val == loss_val, "loss is NaN"
 
     if rank == 0:
+        assert joined == world, f"{joined} ranks joined the barrier, expected {world}"
         graphs = per_gpu * world * args.steps
         value = graphs / elapsed
         # algorithmic bytes of one scatter-aggregate launch: read messages + index, write 4 aggregates
@@ -208,14 +339,17 @@ def main():
                 traffic = None
         flops = 3 * ref_flops_per_graph(cfg) if args.config != 5 else None
         out = {
-            "metric": "molecular graphs/sec (fwd+bwd)", "value": value, "unit": "graphs/s", "n_gpus": world,
+            "metric": "molecular graphs/sec (fwd+bwd)", "value": value, "unit": "graphs/s", "n_gpus": joined,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {cfg['conv']} hidden={H} L={cfg['propagation_depth']} "
                                    f"towers={T} pre={cfg['pre_layers']} post={cfg['post_layers']}, {per_gpu} graphs/GPU "
                                    f"({N_nodes} atoms, {E_edges} directed bonds), fwd+loss+bwd incl. CSR packing",
                        "graphs_per_gpu": per_gpu, "parallelism": f"dp{world}", "hip_graph": graphed,
-                       "grad_allreduce_bytes": flat.nbytes if world > 1 else 0},
+                       "grad_allreduce_bytes": flat.nbytes if flat.collective else 0,
+                       "grad_exchange": ("rccl, %d per-layer slices overlapped with backward + 1" % len(flat.layer_slices)
+                                         if flat._overlap else ("rccl, one call after backward" if flat.collective
+                                                                else "none (1 rank)"))},
             "loss": loss_val,
             "roofline": {"bound": "hbm", "kernel": "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -101,6 +101,18 @@ extern "C" int32_t gnx_side_begin(gnx_handle* h) {
   return GNX_OK;
 }
 
+extern "C" int32_t gnx_side_stream(gnx_handle* h, void** hip_stream) {
+  GNX_CHECK_ARG(h != nullptr && hip_stream != nullptr, "gnx_side_stream: NULL argument");
+  if (h->side == nullptr) {
+    GNX_HIP(hipSetDevice(h->device));
+    GNX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+  }
+  *hip_stream = reinterpret_cast<void*>(h->side);
+  return GNX_OK;
+}
+
 extern "C" int32_t gnx_side_end(gnx_handle* h) {
   GNX_CHECK_ARG(h != nullptr, "gnx_side_end: handle is NULL");
   if (h->on_side) {
@@ -189,6 +201,21 @@ extern "C" int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v) {
   if (n == 0) return GNX_OK;
   int blocks = (int)(gnx_cdiv(n, 256) < 2048 ? gnx_cdiv(n, 256) : 2048);
   hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, h->stream, p, n, v);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+__global__ void k_scale(float* __restrict__ p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] *= v;
+}
+
+extern "C" int32_t gnx_scale(gnx_handle* h, float* p, int64_t n, float v) {
+  GNX_CHECK_ARG(h && (p || n == 0) && n >= 0, "gnx_scale: bad argument");
+  if (n == 0) return GNX_OK;
+  int blocks = (int)(gnx_cdiv(n, 256) < 2048 ? gnx_cdiv(n, 256) : 2048);
+  hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(256), 0, h->stream, p, n, v);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }

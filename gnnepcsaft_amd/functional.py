@@ -128,7 +128,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm([(dy, None, weight)], _empty(x.size(0), x.size(1), x), b_trans=False)
-        ops.finish_backward(dy.device, sw is not None and (sb is not None or not ctx.has_bias))
+        ops.finish_backward(dy.device, sw is not None and (sb is not None or not ctx.has_bias), ctx.sinks)
         return dx, (None if sw is not None else dw), (None if (sb is not None or not ctx.has_bias) else db)
 
 
@@ -343,7 +343,7 @@ class PNAConvFn(torch.autograd.Function):
         ops.queue_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
         dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
         ops.flush_wgrads()  # the layer's weight gradients in batched launches on the weight-gradient stream
-        ops.finish_backward(x.device, all(sk is not None for sk in sinks))
+        ops.finish_backward(x.device, all(sk is not None for sk in sinks), sinks)
         return (dx, dBE, None, None, *[None if sk is not None else g_ for g_, sk in zip(grads, sinks)])
 
 
@@ -387,6 +387,6 @@ class GINEConvFn(torch.autograd.Function):
         dx, dLe = ops.gine_aggregate_bwd(dagg, x, Le, pack, ctx.eps)
         ops.gemm_wgrad(dLe, BE, dlw, dbias=dlb)
         dBE = ops.gemm([(dLe, None, lin_w)], _empty(BE.size(0), BE.size(1), x), b_trans=False)
-        ops.finish_backward(x.device, all(k is not None for k in sk))
+        ops.finish_backward(x.device, all(k is not None for k in sk), sk)
         outs = [None if k is not None else g_ for g_, k in zip((dlw, dlb, dw0, db0, dw2, db2), sk)]
         return (dx, dBE, None, None, *outs)

@@ -404,12 +404,45 @@ def join_side_stream_at_end_of_backward() -> None:
         torch.autograd.Variable._execution_engine.queue_callback(_join_all_side_streams)
 
 
-def finish_backward(device: torch.device, all_in_place: bool) -> None:
+_WGRAD_DONE_HOOK = None
+
+
+def set_wgrad_done_hook(fn) -> None:
+    """``fn(sinks)`` is called at the end of every conv / Linear backward whose weight gradients all went into
+    persistent in-place sinks, right after their launches were issued (on the side stream when enabled): the
+    data-parallel exchange uses it to start a layer's slice of the all-reduce while backward continues."""
+    global _WGRAD_DONE_HOOK
+    _WGRAD_DONE_HOOK = fn
+
+
+def side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The library's weight-gradient stream as a torch stream object (no ownership)."""
+    out = C.c_void_p()
+    check(_lib.load().gnx_side_stream(handle(device), C.byref(out)))
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def wgrad_stream_enabled() -> bool:
+    return _SIDE_ENABLED
+
+
+def scale_(t: torch.Tensor, v: float) -> torch.Tensor:
+    """t *= v through a gnx launch (flat fp32 HIP buffers; anything else falls back to torch's mul_)."""
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
+        if t.numel():
+            check(_lib.load().gnx_scale(handle(t.device), t.data_ptr(), t.numel(), float(v)))
+        return t
+    return t.mul_(v)
+
+
+def finish_backward(device: torch.device, all_in_place: bool, sinks=None) -> None:
     """Last call of an autograd backward that issued weight-gradient launches.  ``all_in_place``: every destination of
     those launches is a persistent gradient buffer nobody reads before the backward pass ends -> one deferred join for
     the whole pass.  Otherwise the Function is about to return fresh tensors that autograd accumulates on the main
     stream immediately -> the main stream waits for the side stream now."""
     if all_in_place:
+        if _WGRAD_DONE_HOOK is not None and sinks:
+            _WGRAD_DONE_HOOK(sinks)
         join_side_stream_at_end_of_backward()
     else:
         join_side_stream(device)

@@ -303,6 +303,9 @@ int32_t gnx_sgd(gnx_handle* h, float* p, const float* g, int64_t n, float lr);
 
 /* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
 int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
+/* p[i] *= v : the 1/world factor of the gradient average after the all-reduce (sum) of the flat gradient buffer
+ * (DDP's averaging; ref: train/train.py:85-88 strategy="auto"). */
+int32_t gnx_scale(gnx_handle* h, float* p, int64_t n, float v);
 
 /* Second stream for work that is independent of the caller's stream (the weight gradients of a layer's backward;
  * stands in for what the reference gets from autograd's per-op CUDA streams under DDP, ref: train/train.py:85-88).
@@ -310,6 +313,10 @@ int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
  *   launch until gnx_side_end goes to the side stream.  gnx_side_join: the bound stream waits for the side stream.
  * Buffers touched by side-stream launches must stay allocated until the join (the caller keeps them alive). */
 int32_t gnx_side_begin(gnx_handle* h);
+/* the side stream itself (created on first use), so that the caller can order OTHER work behind the weight-gradient
+ * launches without a host sync: the data-parallel exchange issues a layer's slice of the gradient all-reduce on it
+ * (torch.cuda.ExternalStream) while the input-gradient chain of the remaining layers keeps the main stream busy. */
+int32_t gnx_side_stream(gnx_handle* h, void** hip_stream);
 int32_t gnx_side_end(gnx_handle* h);
 int32_t gnx_side_join(gnx_handle* h);
 /* y[m,:] = clip(x[m,:], lo[:], hi[:]), NaN propagates like Tensor.clip  (pred_with_bounds, ref: train/models.py:246-253) */

@@ -57,7 +57,21 @@ def _worker(rank, world, port, outdir):
     flat.zero_grad()
     shard = shard_by_graph(batch, world, rank)
     loss = _shard_grads_keep(model, shard)
-    flat.all_reduce()
+    if world == 2:
+        # the overlapped form: every conv layer's slice on its own (in backward order, as the hook issues them), then
+        # the remainder, then ONE scale -- must equal the single-call form the world-4 run uses
+        assert len(flat.layer_slices) == 2 and all(hi > lo for lo, hi in flat.layer_slices)
+        for lo, hi in reversed(flat.layer_slices):
+            flat.reduce_slice(lo, hi)
+        works = flat.all_reduce(async_op=True)
+        assert len(works) == 3  # 2 layer slices + everything after them (the oracle registers its convs first)
+        flat.finish()
+        flat.zero_grad()
+        # a second step through the same object: zero_grad reset the bookkeeping
+        loss = _shard_grads_keep(model, shard)
+        flat.all_reduce()
+    else:
+        flat.all_reduce()
     logged = dp.reduce_logged({"train_huber": loss})
     torch.save({"flat": flat.flat.clone(), "logged": logged, "nbytes": flat.nbytes,
                 "w0": next(model.parameters()).detach().clone()}, os.path.join(outdir, f"r{rank}.pt"))

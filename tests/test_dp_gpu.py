@@ -46,11 +46,17 @@ def _worker(rank, world, port, outdir):
     Fn.set_grad_in_place(True)
     ops.set_wgrad_side_stream(True)
     shard = shard_by_graph(batch, world, rank).to(dev)
-    flat.zero_grad()
-    loss = model.training_step(shard, 0)
-    loss.backward()
+    flat.enable_overlap(True)  # conv-layer slices leave during backward, on the weight-gradient stream
+    for _ in range(2):  # second round: zero_grad resets the slice bookkeeping
+        flat.zero_grad()
+        shard._gnx_pack = None
+        loss = model.training_step(shard, 0)
+        loss.backward()
+        assert len(flat._works) == len(flat.layer_slices) == 2, "one slice per conv layer must be in flight after backward"
+        flat.all_reduce(async_op=True)
+        flat.finish()
     torch.cuda.synchronize()
-    flat.all_reduce()
+    flat.enable_overlap(False)
     logged = dp.reduce_logged(model.logged_metrics)
     torch.save({"flat": flat.flat.cpu(), "logged": logged}, os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
@@ -88,3 +94,22 @@ def test_dp_two_ranks_on_hip_path(gpu_device):
         err = float((outs[r]["flat"] - want).abs().max()) / float(want.abs().max())
         assert err <= 1e-5, err
         assert abs(outs[r]["logged"]["train_huber"] - sum(losses) / world) <= 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_rccl_exchange_path_with_one_rank(gpu_device):
+    """The nccl (= RCCL) backend on the one GPU of this box: `bench.py --gpus 1 --force-dp` initialises the process
+    group, broadcasts, runs the per-layer overlapped slices and the remainder through RCCL and scales -- every call
+    the N-GPU run makes, with world size 1 (two ranks cannot share a device under RCCL).  Run as a child process: it
+    owns its process group."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "3",
+                        "--warmup", "2", "--batch", "512", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["grad_allreduce_bytes"] == 2204931 * 4
+    assert "per-layer slices" in out["config"]["grad_exchange"] and out["loss"] == out["loss"]

@@ -3,6 +3,7 @@ generator invariants, C-ABI library loads and exports every symbol include/gnx.h
 construction / state-dict / error surface, and that the product path refuses to run without a HIP device."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -281,3 +282,51 @@ def test_lightning_style_checkpoint_with_configdict_is_read_without_executing_it
     assert ckpt["global_step"] == 7 and ckpt["hyper_parameters"]["config"] == cfg
     assert torch.equal(ckpt["state_dict"]["model.mlp.6.weight"], sd["model.mlp.6.weight"])
     assert not any(n in sys.modules for n in names)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py launcher: `--gpus N` must really be N ranks (it used to run one rank silently)
+# ---------------------------------------------------------------------------------------------------------------
+def _run_bench(argv, env_extra=None, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["steps"] == 2 and out["warmup"] == 1
+
+
+def test_bench_under_torchrun_is_one_of_the_ranks():
+    """The driver's launch line: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, r.stdout
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+    if torch.cuda.device_count() < 3:
+        r = _run_bench(["--gpus", "3", "--steps", "1"])  # real run: needs 3 visible devices
+        assert r.returncode == 2 and "HIP device(s) visible" in r.stderr
