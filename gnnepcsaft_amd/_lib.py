@@ -96,6 +96,7 @@ SIGNATURES = {
     "gnx_sgd": (_i32, [_vp, _vp, _vp, _i64, _f32]),
     "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),
     "gnx_scale": (_i32, [_vp, _vp, _i64, _f32]),
+    "gnx_axpy": (_i32, [_vp, _vp, _vp, _i64, _f32]),
     "gnx_side_stream": (_i32, [_vp, C.POINTER(_vp)]),
     "gnx_side_begin": (_i32, [_vp]),
     "gnx_side_end": (_i32, [_vp]),

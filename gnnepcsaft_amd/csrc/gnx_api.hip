@@ -220,6 +220,21 @@ extern "C" int32_t gnx_scale(gnx_handle* h, float* p, int64_t n, float v) {
   return GNX_OK;
 }
 
+__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = fmaf(a, x[i], y[i]);
+}
+
+extern "C" int32_t gnx_axpy(gnx_handle* h, float* y, const float* x, int64_t n, float a) {
+  GNX_CHECK_ARG(h && ((y && x) || n == 0) && n >= 0, "gnx_axpy: bad argument");
+  if (n == 0) return GNX_OK;
+  int blocks = (int)(gnx_cdiv(n, 256) < 2048 ? gnx_cdiv(n, 256) : 2048);
+  hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, h->stream, y, x, n, a);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
 __global__ void k_clip_rows(const float* __restrict__ x, int64_t M, int P, const float* __restrict__ lo,
                             const float* __restrict__ hi, float* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

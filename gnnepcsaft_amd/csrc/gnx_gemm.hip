@@ -1818,7 +1818,10 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.vec_y = aligned16(A) && (lda % 4 == 0);
   int64_t tiles = gnx_cdiv(N, BN) * gnx_cdiv(K, BN);
   // aim for ~512 workgroups; at least 128 rows each (4 K-steps) so the atomic flush stays amortised
-  const int64_t target_wgs = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? h->opt[GNX_OPT_WGRAD_WGS] : 512;
+  // default: one workgroup per CU.  Measured on cfg-2 (tools/ab_bench.py, same box): 512 / 1024 workgroups cost 0.4 ms
+  // per step more -- every workgroup flushes its 128 x 128 partial sum with fp32 atomics, and a weight-gradient launch
+  // that fills every CU slot starves the input-gradient chain it overlaps with on the main stream.
+  const int64_t target_wgs = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? h->opt[GNX_OPT_WGRAD_WGS] : (h->num_cus > 0 ? h->num_cus : 256);
   int64_t chunks = gnx_cdiv(target_wgs, tiles);
   int64_t rows = gnx_cdiv(gnx_cdiv(M, chunks), BK) * BK;
   if (rows < 128) rows = 128;
@@ -1978,7 +1981,7 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
     if (i >= nprob) continue;
     const int tn = (int)gnx_cdiv(b.p[i].N, BN), tk = (int)gnx_cdiv(b.p[i].K, BN);
     const int64_t M = b.p[i].M > 0 ? b.p[i].M : 1;
-    const double budget = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? (double)h->opt[GNX_OPT_WGRAD_WGS] : 1024.0;
+    const double budget = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? (double)h->opt[GNX_OPT_WGRAD_WGS] : (double)(h->num_cus > 0 ? h->num_cus : 256);
     int64_t chunks = (int64_t)(budget * ((double)M * tn * tk / total_cost) / (tn * tk) + 0.5);
     const int64_t max_chunks = gnx_cdiv(M, 128);
     if (chunks > max_chunks) chunks = max_chunks;

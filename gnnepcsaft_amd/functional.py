@@ -16,6 +16,24 @@ from .ops import GraphPack
 
 _GRAD_IN_PLACE = False
 _USE_DEGREE_CLASSES = True
+_MERGE_LAST_POST = True
+_PREPARE_AHEAD = True
+
+
+def set_merge_last_post(enabled: bool) -> None:
+    """A/B switch: PNA's last post layer and ``lin`` as ONE product with a merged H x H weight (default on)."""
+    global _MERGE_LAST_POST
+    _MERGE_LAST_POST = bool(enabled)
+
+
+def set_prepare_ahead(enabled: bool) -> None:
+    """A/B switch: the model issues a PNA layer's weight-only launches one layer ahead on the side stream (default on)."""
+    global _PREPARE_AHEAD
+    _PREPARE_AHEAD = bool(enabled)
+
+
+def prepare_ahead_enabled() -> bool:
+    return _PREPARE_AHEAD
 
 
 def set_degree_classes(enabled: bool) -> None:
@@ -190,6 +208,75 @@ class HuberAPEFn(torch.autograd.Function):
         return dpred * dloss, None, None
 
 
+def _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
+    """Everything a PNAConv forward needs that depends on the weights alone (plus the number of degree classes D, 0 =
+    ungrouped): EE = BondEmb W_enc^T + b_enc [R,F];  Te = per tower EE W_e^T + b (the edge part of pre-layer 0 on the
+    60-row bond table) [R,H];  Weff(d) per tower;  the merged (lin o last post layer) weight / bias."""
+    R, H = BE.size(0), T * F
+    enc_w, enc_b, lin_w, lin_b = params[:4]
+    per = 2 * (pre_layers + post_layers)
+    sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+    EE = ops.gemm([(BE, None, enc_w)], _empty(R, F, BE), bias=enc_b)
+    Te = _empty(R, H, BE)
+    weffs, last = [], []
+    for t in range(T):
+        W0, b0 = params[4 + t * per], params[4 + t * per + 1]
+        ops.gemm([(EE, None, W0[:, 2 * F:3 * F])], Te[:, sl[t]], bias=b0)
+        Wp = params[4 + t * per + 2 * pre_layers]
+        if D > 0:
+            weffs.append(ops.pna_weff(Wp, F, D, avg_deg_log))
+        k = 4 + t * per + 2 * (pre_layers + post_layers - 1)
+        last.append((params[k], params[k + 1]))
+    Wm = bm = None
+    if post_layers > 1 and _MERGE_LAST_POST:
+        Wm, bm = _merge_last_post_with_lin(lin_w, lin_b, last, sl, BE)
+    return EE, Te, weffs, Wm, bm
+
+
+class WeightOnlyAhead:
+    """``_pna_weight_only`` issued on the library's side stream (when enabled) so that its ~5 tiny dependent launches
+    leave the critical path: the model issues layer l+1's while layer l runs.  ``wait()`` orders the caller's stream
+    behind them and returns the tensors."""
+
+    def __init__(self, BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
+        self.device = BE.device
+        with torch.no_grad():
+            box = []
+            args = (BE.detach(), T, F, pre_layers, post_layers, avg_deg_log, [p.detach() for p in params], D)
+            ops.run_after_wgrads(BE, (), lambda: box.append(_pna_weight_only(*args)))
+            self.value = box[0]
+
+    def wait(self):
+        ops.join_side_stream(self.device)
+        return self.value
+
+
+def _merge_last_post_with_lin(lin_w, lin_b, last, sl, like):
+    """Wm [H,H], bm [H] with  lin(cat_t(post_last_t(z_t))) = z Wm^T + bm  (``last`` = [(W_t, b_t)] per tower)."""
+    H = lin_w.size(0)
+    Wm, bm = _empty(H, H, like), _empty(1, H, like)
+    for t, (Wt, _) in enumerate(last):
+        ops.gemm([(lin_w[:, sl[t]], None, Wt)], Wm[:, sl[t]], b_trans=False)       # [H,F] @ [F,F]
+    for t, (_, bt) in enumerate(last):  # bm = lin_b + sum_t b_t @ lin_w[:, t]^T   (no torch.cat: may run on the side stream)
+        ops.gemm([(bt.view(1, -1), None, lin_w[:, sl[t]])], bm, bias=lin_b if t == 0 else None, accumulate=t > 0)
+    return Wm, bm.view(-1)
+
+
+def _unmerge_last_post_and_lin(dWm, dbm, lin_w, d_lin_w, d_lin_b, last, last_bias, sl):
+    """Accumulates (+=) the gradients of ``lin`` and of the last post layer from those of the merged product
+    (u_t = z_t W_t^T + b_t is the last post layer's output, which is never formed):
+    d lin_w[:, t] += dout^T u_t = dWm[:, t] W_t^T + dbm b_t^T ;  dW_t += lin_w[:, t]^T dWm[:, t] ;
+    db_t += dbm lin_w[:, t] ;  d lin_b += dbm."""
+    row, col = dbm.view(1, -1), dbm.view(-1, 1)
+    for t, (Wt, dWt, dbt) in enumerate(last):
+        bt = last_bias[t]
+        ops.gemm([(dWm[:, sl[t]], None, Wt)], d_lin_w[:, sl[t]], accumulate=True)                   # [H,F] @ [F,F]^T
+        ops.gemm([(col, None, bt.view(-1, 1))], d_lin_w[:, sl[t]], accumulate=True)                  # [H,1] @ [F,1]^T
+        ops.gemm_wgrad_inline(lin_w[:, sl[t]], dWm[:, sl[t]], dWt)                                   # [H,F]^T [H,F]
+        ops.gemm([(row, None, lin_w[:, sl[t]])], dbt.view(1, -1), b_trans=False, accumulate=True)    # [1,H] @ [H,F]
+    ops.axpy_(d_lin_b, dbm)
+
+
 class PNAConvFn(torch.autograd.Function):
     """[3P] torch_geometric.nn.PNAConv(aggregators=[mean,min,max,std], scalers=[identity,amplification,attenuation],
     towers=T, pre_layers, post_layers, divide_input=True) as built at models.py:445-457.
@@ -203,7 +290,7 @@ class PNAConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, BE, pack: GraphPack, cfg, *params):
-        T, F, pre_layers, post_layers, avg_deg_log = cfg
+        T, F, pre_layers, post_layers, avg_deg_log, prep = cfg
         x = x.contiguous()
         N, H = x.shape
         E, R = pack.E, BE.size(0)
@@ -214,12 +301,18 @@ class PNAConvFn(torch.autograd.Function):
         post = [[(params[4 + t * per + 2 * (pre_layers + i)], params[4 + t * per + 2 * (pre_layers + i) + 1])
                  for i in range(post_layers)] for t in range(T)]
         sl = [slice(t * F, (t + 1) * F) for t in range(T)]
-        EE = ops.gemm([(BE, None, enc_w)], _empty(R, F, x), bias=enc_b)
-        Te, P, Q = _empty(R, H, x), _empty(N, H, x), _empty(N, H, x)
+        # degree classes: amp/att depend on the in-degree only, so with rows grouped by degree class the 12F-wide scaled
+        # operand of post-layer 0 collapses to A @ Weff(d)^T; hub-heavy batches (> 64 classes) keep 4 segments
+        dc = pack.degree_classes(pack.max_degree_hint) if _USE_DEGREE_CLASSES else None
+        # everything that depends on the WEIGHTS only (60-row bond-table chain, Weff(d), lin o last post layer): taken
+        # from ``prep`` when the caller evaluated it ahead of time on the side stream (pna_weight_only_async)
+        if prep is None:
+            prep = _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, dc.D if dc is not None else 0)
+        EE, Te, weffs, Wm, bm = prep
+        P, Q = _empty(N, H, x), _empty(N, H, x)
         for t in range(T):
-            W0, b0 = pre[t][0]
+            W0 = pre[t][0][0]
             xt = x[:, sl[t]]
-            ops.gemm([(EE, None, W0[:, 2 * F:3 * F])], Te[:, sl[t]], bias=b0)
             ops.gemm([(xt, None, W0[:, 0:F])], P[:, sl[t]])
             ops.gemm([(xt, None, W0[:, F:2 * F])], Q[:, sl[t]])
         h = ops.edge_combine_fwd(P, Q, Te, pack, relu=pre_layers > 1)
@@ -234,34 +327,35 @@ class PNAConvFn(torch.autograd.Function):
         A = ops.pna_aggregate_fwd(h, pack, T, F)
         amp, att = pack.degree_scalers(avg_deg_log)
         z = _empty(N, H, x)
-        # post-layer 0: amp/att depend on the in-degree only, so with rows grouped by degree class the 12F-wide scaled
-        # operand collapses to A @ Weff(d)^T (26NF^2 -> 10NF^2 FLOPs); hub-heavy batches (>64 classes) keep 4 segments
-        dc = pack.degree_classes(pack.max_degree_hint) if _USE_DEGREE_CLASSES else None
-        weffs = []
         for t in range(T):
             Wp, bp = post[t][0]
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
             if dc is not None:
-                weff = ops.pna_weff(Wp, F, dc.D, avg_deg_log)
-                weffs.append(weff)
-                ops.gemm_grouped([(x[:, sl[t]], None, Wp[:, 0:F], 0), (At, None, weff[0], 4 * F * F)], z[:, sl[t]], dc,
+                ops.gemm_grouped([(x[:, sl[t]], None, Wp[:, 0:F], 0), (At, None, weffs[t][0], 4 * F * F)], z[:, sl[t]], dc,
                                  bias=bp, relu=post_layers > 1)
             else:
                 ops.gemm([(x[:, sl[t]], None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
                           (At, att, Wp[:, 9 * F:13 * F])], z[:, sl[t]], bias=bp, relu=post_layers > 1)
         zs = [z]
-        for i in range(1, post_layers):
+        merged = Wm is not None
+        for i in range(1, post_layers - 1 if merged else post_layers):
             zn = _empty(N, H, x)
             for t in range(T):
                 Wi, bi = post[t][i]
                 ops.gemm([(z[:, sl[t]], None, Wi)], zn[:, sl[t]], bias=bi, relu=i < post_layers - 1)
             z = zn
             zs.append(z)
-        out = ops.gemm([(z, None, lin_w)], _empty(N, H, x), bias=lin_b)
-        ctx.pack, ctx.cfg = pack, cfg
+        if merged:
+            # The last post layer has no activation and feeds ``lin`` directly: lin(post_last(z)) = z Wm^T + bm with
+            # Wm[:, tower t] = lin_w[:, tower t] @ W_last_t  and  bm = lin_w @ b_last + lin_b  (H x H, from the weights
+            # alone) -- one [N, H] product and one [N, H] round trip less, forward and backward.
+            out = ops.gemm([(z, None, Wm)], _empty(N, H, x), bias=bm)
+        else:
+            out = ops.gemm([(z, None, lin_w)], _empty(N, H, x), bias=lin_b)
+        ctx.pack, ctx.cfg = pack, cfg[:5]
         ctx.n_h, ctx.n_z = len(hs), len(zs)
         ctx.sinks = grad_sinks(params)
-        ctx.dc, ctx.weffs = dc, weffs
+        ctx.dc, ctx.weffs, ctx.Wm = dc, weffs, Wm
         ctx.save_for_backward(x, BE, EE, A, amp, att, *hs, *zs, *params)
         return out
 
@@ -287,11 +381,22 @@ class PNAConvFn(torch.autograd.Function):
 
         sl = [slice(t * F, (t + 1) * F) for t in range(T)]
         dout = dout.contiguous()
-        # lin
-        ops.queue_wgrad(dout, zs[-1], d_lin_w, dbias=d_lin_b)
-        g = ops.gemm([(dout, None, lin_w)], _empty(N, H, x), b_trans=False)
-        # post layers last..1 : dgrad masked by the relu'd input activation
-        for i in range(post_layers - 1, 0, -1):
+        merged = None
+        if ctx.Wm is not None:
+            # lin o post_last as one product with Wm (see forward): dWm = dout^T z, dbm = sum dout, dz = dout Wm masked by
+            # z > 0; the gradients of lin and of the last post layer follow from dWm / dbm by H x H products (queued
+            # behind the weight-gradient launch that produces dWm)
+            dWm, dbm = _zeros_like(ctx.Wm), ops.zeros(H, device=x.device)
+            ops.queue_wgrad(dout, zs[-1], dWm, dbias=dbm)
+            g = ops.gemm([(dout, None, ctx.Wm)], _empty(N, H, x), b_trans=False, mask=zs[-1])
+            merged = (dWm, dbm)
+            last_hidden = post_layers - 2
+        else:
+            ops.queue_wgrad(dout, zs[-1], d_lin_w, dbias=d_lin_b)
+            g = ops.gemm([(dout, None, lin_w)], _empty(N, H, x), b_trans=False)
+            last_hidden = post_layers - 1
+        # hidden post layers last..1 : dgrad masked by the relu'd input activation
+        for i in range(last_hidden, 0, -1):
             a_prev = zs[i - 1]
             gn = _empty(N, H, x)
             for t in range(T):
@@ -343,6 +448,13 @@ class PNAConvFn(torch.autograd.Function):
         ops.queue_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
         dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
         ops.flush_wgrads()  # the layer's weight gradients in batched launches on the weight-gradient stream
+        if merged is not None:
+            dWm, dbm = merged
+            last = [(params[pidx(t, "post", post_layers - 1)], grads[pidx(t, "post", post_layers - 1)],
+                     grads[pidx(t, "post", post_layers - 1) + 1]) for t in range(T)]
+            last_bias = [params[pidx(t, "post", post_layers - 1) + 1] for t in range(T)]
+            ops.run_after_wgrads(dout, (dWm, dbm, lin_w, d_lin_w, d_lin_b),
+                                 lambda: _unmerge_last_post_and_lin(dWm, dbm, lin_w, d_lin_w, d_lin_b, last, last_bias, sl))
         ops.finish_backward(x.device, all(sk is not None for sk in sinks), sinks)
         return (dx, dBE, None, None, *[None if sk is not None else g_ for g_, sk in zip(grads, sinks)])
 

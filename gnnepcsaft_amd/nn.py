@@ -155,16 +155,26 @@ class PNAConv(Module):
             self.post_nns.append(_Seq(*mods))
         self.lin = Linear(out_channels, out_channels)
 
-    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor) -> torch.Tensor:
-        """x fp32[N,H]; edge_index: GraphPack of the batch; edge_attr: fp32[60,H] encoded bond table."""
+    def _params(self):
         params = [self.edge_encoder.weight, self.edge_encoder.bias, self.lin.weight, self.lin.bias]
         for t in range(self.towers):
             for lin in self.pre_nns[t].linears():
                 params += [lin.weight, lin.bias]
             for lin in self.post_nns[t].linears():
                 params += [lin.weight, lin.bias]
-        cfg = (self.towers, self.F_in, self.pre_layers, self.post_layers, self.aggr_module.avg_log())
-        return Fn.PNAConvFn.apply(x, edge_attr, edge_index, cfg, *params)
+        return params
+
+    def prepare_ahead(self, edge_index: GraphPack, edge_attr: torch.Tensor) -> "Fn.WeightOnlyAhead":
+        """Issue this layer's weight-only work (bond-table chain, Weff(d), merged lin o last post layer) on the side
+        stream now; pass ``.wait()`` of the result to ``forward(prepared=...)``.  The model does this one layer ahead."""
+        dc = edge_index.degree_classes(edge_index.max_degree_hint) if Fn._USE_DEGREE_CLASSES else None
+        return Fn.WeightOnlyAhead(edge_attr, self.towers, self.F_in, self.pre_layers, self.post_layers,
+                                  self.aggr_module.avg_log(), self._params(), dc.D if dc is not None else 0)
+
+    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor, prepared=None) -> torch.Tensor:
+        """x fp32[N,H]; edge_index: GraphPack of the batch; edge_attr: fp32[60,H] encoded bond table."""
+        cfg = (self.towers, self.F_in, self.pre_layers, self.post_layers, self.aggr_module.avg_log(), prepared)
+        return Fn.PNAConvFn.apply(x, edge_attr, edge_index, cfg, *self._params())
 
 
 class GINEConv(Module):

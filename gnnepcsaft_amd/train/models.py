@@ -152,9 +152,19 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
             pack = ops.pack_graph(edge_index, edge_attr, batch, x.size(0), None, validate=self.validate_inputs)
         h = self.node_embed(x)
         bond_table = self.edge_embed.table()  # 60 encoded bond-feature combinations; edges index it by pack.code
-        for layer, norm in zip(self.convs, self.batch_norms):
+        # weight-only work of PNA layer l+1 (bond-table chain, Weff(d), merged lin o last post layer: ~5 tiny dependent
+        # launches) is issued on the library's side stream while layer l runs, so it leaves the critical path
+        convs = list(self.convs)
+        ahead = None
+        if h.is_cuda and ops.wgrad_stream_enabled() and Fn.prepare_ahead_enabled() and hasattr(convs[0], "prepare_ahead"):
+            ahead = convs[0].prepare_ahead(pack, bond_table)
+        for l, (layer, norm) in enumerate(zip(convs, self.batch_norms)):
+            extra = {}
+            if ahead is not None:
+                extra["prepared"] = ahead.wait()
+                ahead = convs[l + 1].prepare_ahead(pack, bond_table) if l + 1 < len(convs) else None
             # PNA and GINE both take edge_attr (reference :211-214); the ReLU is fused into the BatchNorm kernel
-            h = norm(layer(x=self.dropout(h), edge_index=pack, edge_attr=bond_table), relu=True)
+            h = norm(layer(x=self.dropout(h), edge_index=pack, edge_attr=bond_table, **extra), relu=True)
         if batch is not None or pack.has_batch:
             h = self.global_pool(h, pack)
         else:  # batch None: reduce over all rows, keepdim (reference :220-225)

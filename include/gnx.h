@@ -55,7 +55,7 @@ enum {
   GNX_OPT_GEMM_WS = 1,           /* 1: weights-stationary kernel for one segment with K, N <= 128, M >= 8192 */
   GNX_OPT_GEMM_VEC = 2,          /* 0: element-wise loaders everywhere (debug) */
   GNX_OPT_WGRAD_VEC = 3,         /* 0: element-wise weight-gradient loaders (debug) */
-  GNX_OPT_WGRAD_WGS = 4,         /* > 0: target workgroup count of the weight-gradient kernels */
+  GNX_OPT_WGRAD_WGS = 4,         /* > 0: target workgroup count of the weight-gradient kernels (default: #CUs) */
   GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
   GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 4096 */
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
@@ -306,6 +306,8 @@ int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
 /* p[i] *= v : the 1/world factor of the gradient average after the all-reduce (sum) of the flat gradient buffer
  * (DDP's averaging; ref: train/train.py:85-88 strategy="auto"). */
 int32_t gnx_scale(gnx_handle* h, float* p, int64_t n, float v);
+/* y[i] += a * x[i] : bias gradient of ``lin`` from the merged (lin o last post layer) product of PNAConv's backward. */
+int32_t gnx_axpy(gnx_handle* h, float* y, const float* x, int64_t n, float a);
 
 /* Second stream for work that is independent of the caller's stream (the weight gradients of a layer's backward;
  * stands in for what the reference gets from autograd's per-op CUDA streams under DDP, ref: train/train.py:85-88).

@@ -233,6 +233,7 @@ def run_conv_case(kind: str, H: int, batch, *, towers: int = 1, pre_layers: int 
                 worst_max, name = e_max, n
             worst_l2 = max(worst_l2, _l2(gg[n], ref) if float(ref.norm()) > 1e-3 * G else 0.0)
         r[f"dparam_max_{tag}"], r[f"dparam_l2_{tag}"], r[f"dparam_argmax_{tag}"] = worst_max, worst_l2, name
+        r[f"dparam_each_{tag}"] = {n: float(f"{rel_err(gg[n], ref, floor=1e-3 * G):.2e}") for n, ref in g64.items()}
     return r
 
 

