@@ -17,8 +17,15 @@ OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG
     OPT_STD_BWD_CENTERED = range(8)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
-K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
-    K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD = range(11)
+K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
+    K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD, K_GEMM_TILED, K_GEMM_SMALL, K_GEMM_WGRAD_BATCHED, K_KEY_SEGMENT_SUM, \
+    K_EMBED = range(16)
+K_COUNT = 16
+KERNEL_GROUPS = {K_PNA_AGG_FWD: "pna_aggregate_fwd", K_PNA_AGG_BWD: "pna_aggregate_bwd", K_GEMM_WS: "gemm_weights_stationary",
+                 K_GEMM_WGRAD: "weight_gradient", K_GINE_AGG_FWD: "gine_aggregate_fwd", K_GINE_AGG_BWD: "gine_aggregate_bwd",
+                 K_EDGE_COMBINE_FWD: "edge_combine_fwd", K_EDGE_COMBINE_BWD: "edge_combine_bwd", K_BN_FWD: "batchnorm_fwd",
+                 K_BN_BWD: "batchnorm_bwd", K_GEMM_TILED: "gemm_tiled", K_GEMM_SMALL: "gemm_small",
+                 K_GEMM_WGRAD_BATCHED: "weight_gradient_batched", K_KEY_SEGMENT_SUM: "key_segment_sum", K_EMBED: "embedding"}
 
 
 class GnxError(RuntimeError):
@@ -50,7 +57,8 @@ SIGNATURES = {
     "gnx_set_option": (_i32, [_vp, _i32, _i32]),
     "gnx_get_option": (_i32, [_vp, _i32, C.POINTER(_i32)]),
     "gnx_prof_begin": (_i32, [_vp, C.c_uint32]),
-    "gnx_prof_read": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "gnx_prof_read": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gnx_prof_end": (_i32, [_vp]),
     "gnx_pack_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "gnx_pack_csr": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
@@ -80,9 +88,9 @@ SIGNATURES = {
     "gnx_key_segment_sum": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "gnx_edge_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz]),
-    "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "gnx_pna_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gnx_pna_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "gnx_gine_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                       _vp, _vp]),
     "gnx_segment_pool_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

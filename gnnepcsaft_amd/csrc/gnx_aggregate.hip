@@ -121,12 +121,13 @@ __global__ void __launch_bounds__(256) k_pna_agg_fwd(const float* __restrict__ m
   vstore<VEC>(o + 3 * F, sd);
 }
 
-extern "C" int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int32_t T,
-                                         int32_t F, float* A) {
-  GNX_CHECK_ARG(h && rowptr && T > 0 && F > 0 && N >= 0, "gnx_pna_aggregate_fwd: bad argument");
+extern "C" int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int64_t E,
+                                         int32_t T, int32_t F, float* A) {
+  GNX_CHECK_ARG(h && rowptr && T > 0 && F > 0 && N >= 0 && E >= 0, "gnx_pna_aggregate_fwd: bad argument");
   GNX_CHECK_ARG(N == 0 || A, "gnx_pna_aggregate_fwd: A is NULL");
   if (N == 0) return GNX_OK;
-  gnx_prof_scope prof(h, GNX_K_PNA_AGG_FWD);
+  // algorithmic bytes: read the messages 4EH and the index 4E, write the four aggregates 16NH
+  gnx_prof_scope prof(h, GNX_K_PNA_AGG_FWD, 4.0 * E * T * F + 4.0 * E + 16.0 * N * T * F);
   if (F % 4 == 0) {
     int64_t th = N * (T * F / 4);
     hipLaunchKernelGGL(k_pna_agg_fwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, m, rowptr, N, (int)T,
@@ -312,11 +313,12 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
 }
 
 extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A,
-                                         const int32_t* rowptr, int64_t N, int32_t T, int32_t F, float* dm) {
-  GNX_CHECK_ARG(h && rowptr && T > 0 && F > 0 && N >= 0, "gnx_pna_aggregate_bwd: bad argument");
+                                         const int32_t* rowptr, int64_t N, int64_t E, int32_t T, int32_t F, float* dm) {
+  GNX_CHECK_ARG(h && rowptr && T > 0 && F > 0 && N >= 0 && E >= 0, "gnx_pna_aggregate_bwd: bad argument");
   GNX_CHECK_ARG(N == 0 || (dA && A), "gnx_pna_aggregate_bwd: NULL argument");
   if (N == 0) return GNX_OK;
-  gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD);
+  // read the aggregate gradient 16NH, re-read the messages 4EH + index 4E, write the message gradient 4EH
+  gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD, 16.0 * N * T * F + 8.0 * E * T * F + 4.0 * E);
   {
     if (h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] != 0) {
       if (F % 4 == 0)
@@ -373,7 +375,7 @@ extern "C" int32_t gnx_edge_combine_fwd(gnx_handle* h, const float* P, const flo
   GNX_CHECK_ARG(h && H > 0 && E >= 0, "gnx_edge_combine_fwd: bad argument");
   if (E == 0) return GNX_OK;
   GNX_CHECK_ARG(P && Q && Te && src && dst && code && h1, "gnx_edge_combine_fwd: NULL argument");
-  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_FWD);
+  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_FWD, 12.0 * E * H + 12.0 * E);  // gather P, Q rows, write h; 3 indices
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_edge_combine_fwd<4>, dim3((unsigned)gnx_cdiv(E * (H / 4), 256)), dim3(256), 0, h->stream, P, Q,
                        Te, src, dst, code, E, (int)H, (int)relu, h1);
@@ -425,7 +427,7 @@ extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int
   GNX_CHECK_ARG(h && H > 0 && N >= 0 && E >= 0, "gnx_edge_combine_bwd: bad argument");
   if (N == 0) return GNX_OK;
   GNX_CHECK_ARG(rowptr && colptr && dP && dQ && (E == 0 || (g && cpos)), "gnx_edge_combine_bwd: NULL argument");
-  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_BWD);
+  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_BWD, 4.0 * E * H + 8.0 * N * H + 4.0 * E + 8.0 * N);  // read g once, write dP, dQ
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_edge_combine_bwd<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, g,
                        rowptr, colptr, cpos, N, (int)H, dP, dQ);
@@ -503,6 +505,7 @@ extern "C" int32_t gnx_key_segment_sum(gnx_handle* h, const float* g, const int3
   GNX_CHECK_ARG(h && H > 0 && E >= 0, "gnx_key_segment_sum: bad argument");
   if (E == 0) return GNX_OK;
   GNX_CHECK_ARG(g && pos && key && dtable, "gnx_key_segment_sum: NULL argument");
+  gnx_prof_scope prof(h, GNX_K_KEY_SEGMENT_SUM, 4.0 * E * H + 8.0 * E);
   const unsigned blocks = (unsigned)gnx_cdiv(E, SEG_CHUNK);
   if (H % 4 == 0 && H / 4 <= 256)
     hipLaunchKernelGGL(k_key_segment_sum<4>, dim3(blocks), dim3(256), 0, h->stream, g, pos, key, E, (int)H, dtable);
@@ -548,12 +551,13 @@ __global__ void __launch_bounds__(256) k_gine_fwd(const float* __restrict__ x, c
 }
 
 extern "C" int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const float* Le, const int32_t* rowptr,
-                                          const int32_t* src, const int32_t* code, int64_t N, int32_t H, float eps,
-                                          float* out) {
-  GNX_CHECK_ARG(h && H > 0 && N >= 0, "gnx_gine_aggregate_fwd: bad argument");
+                                          const int32_t* src, const int32_t* code, int64_t N, int64_t E, int32_t H,
+                                          float eps, float* out) {
+  GNX_CHECK_ARG(h && H > 0 && N >= 0 && E >= 0, "gnx_gine_aggregate_fwd: bad argument");
   if (N == 0) return GNX_OK;
   GNX_CHECK_ARG(x && Le && rowptr && out, "gnx_gine_aggregate_fwd: NULL argument");
-  gnx_prof_scope prof(h, GNX_K_GINE_AGG_FWD);
+  // gather x[src] per edge 4EH + two indices 8E, read x and write out 8NH
+  gnx_prof_scope prof(h, GNX_K_GINE_AGG_FWD, 4.0 * E * H + 8.0 * E + 8.0 * N * H);
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_gine_fwd<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, x, Le, rowptr,
                        src, code, N, (int)H, eps, out);
@@ -713,7 +717,8 @@ extern "C" int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, cons
   if (N == 0) return GNX_OK;
   GNX_CHECK_ARG(dout && x && Le && colptr && dx, "gnx_gine_aggregate_bwd: NULL argument");
   GNX_CHECK_ARG(E == 0 || (cpos && src && dst && code), "gnx_gine_aggregate_bwd: NULL edge array with E>0");
-  gnx_prof_scope prof(h, GNX_K_GINE_AGG_BWD);
+  // dx: gather dout[dst] per edge 4EH + indices 8E, read dout and x, write dx 12NH; dLe: another 8EH of gathers
+  gnx_prof_scope prof(h, GNX_K_GINE_AGG_BWD, 4.0 * E * H + 8.0 * E + 12.0 * N * H + (dLe ? 8.0 * E * H : 0.0));
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_gine_bwd_dx<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, dout, x, Le,
                        colptr, cpos, dst, code, N, (int)H, eps, dx);

@@ -164,21 +164,26 @@ extern "C" int32_t gnx_prof_begin(gnx_handle* h, uint32_t kernel_mask) {
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms) {
+extern "C" int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms, double* alg_bytes,
+                                 double* alg_flops, double* mfma_bf16_flops) {
   GNX_CHECK_ARG(h != nullptr && launches != nullptr && total_ms != nullptr, "gnx_prof_read: NULL argument");
   GNX_CHECK_ARG(kid > 0 && kid < GNX_K_COUNT, "gnx_prof_read: bad kernel id %d", kid);
   GNX_HIP(hipStreamSynchronize(h->stream));
-  double tot = 0.0;
+  double tot = 0.0, w[3] = {0.0, 0.0, 0.0};
   int64_t n = 0;
   for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
     if (h->ev_kid[i / 2] != kid) continue;
     float ms = 0.f;
     GNX_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     tot += ms;
+    for (int q = 0; q < 3; ++q) w[q] += h->ev_work[3 * (i / 2) + q];
     ++n;
   }
   *launches = n;
   *total_ms = tot;
+  if (alg_bytes) *alg_bytes = w[0];
+  if (alg_flops) *alg_flops = w[1];
+  if (mfma_bf16_flops) *mfma_bf16_flops = w[2];
   return GNX_OK;
 }
 

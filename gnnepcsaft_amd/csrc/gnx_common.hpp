@@ -27,6 +27,7 @@ struct gnx_handle {
   unsigned prof_mask = 0;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_kid;  // kernel id of the event pair starting at ev[2*i]
+  std::vector<double> ev_work;  // 3 per pair: algorithmic bytes, algorithmic flops, executed bf16-MFMA flops
   size_t ev_used = 0;
 };
 
@@ -62,10 +63,16 @@ void gnx_set_error(const char* fmt, ...);
 struct gnx_prof_scope {
   gnx_handle* h;
   bool on;
-  gnx_prof_scope(gnx_handle* h_, int kid) : h(h_), on(((h_->prof_mask >> kid) & 1u) != 0 && kid != GNX_K_NONE) {
+  gnx_prof_scope(gnx_handle* h_, int kid, double bytes = 0.0, double flops = 0.0, double mfma = 0.0)
+      : h(h_), on(((h_->prof_mask >> kid) & 1u) != 0 && kid != GNX_K_NONE) {
     if (on) {
-      if (h->ev_kid.size() <= h->ev_used / 2) h->ev_kid.resize(h->ev_used / 2 + 1);
-      h->ev_kid[h->ev_used / 2] = kid;
+      const size_t i = h->ev_used / 2;
+      if (h->ev_kid.size() <= i) h->ev_kid.resize(i + 1);
+      if (h->ev_work.size() < 3 * (i + 1)) h->ev_work.resize(3 * (i + 1));
+      h->ev_kid[i] = kid;
+      h->ev_work[3 * i] = bytes;
+      h->ev_work[3 * i + 1] = flops;
+      h->ev_work[3 * i + 2] = mfma;
       mark();
     }
   }

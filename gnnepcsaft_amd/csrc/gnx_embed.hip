@@ -50,6 +50,7 @@ extern "C" int32_t gnx_embed_sum_fwd(gnx_handle* h, const int64_t* idx, int64_t 
   GNX_CHECK_ARG(h && offsets && table && K > 0 && K <= 16 && H > 0 && N >= 0, "gnx_embed_sum_fwd: bad argument");
   GNX_CHECK_ARG(N == 0 || (idx && out), "gnx_embed_sum_fwd: NULL array with N>0");
   if (N == 0) return GNX_OK;
+  gnx_prof_scope prof(h, GNX_K_EMBED, 8.0 * N * K + 4.0 * N * H);
   offs_t o;
   for (int k = 0; k <= 17; ++k) o.o[k] = offsets[k <= K ? k : K];
   if (H % 4 == 0) {
@@ -235,6 +236,7 @@ extern "C" int32_t gnx_embed_sum_bwd(gnx_handle* h, const int64_t* idx, int64_t 
   GNX_CHECK_ARG(N == 0 || (idx && dout), "gnx_embed_sum_bwd: NULL array with N>0");
   GNX_CHECK_ARG(offsets[K] == R, "gnx_embed_sum_bwd: offsets[K]=%d != R=%d", offsets[K], R);
   if (N == 0) return GNX_OK;
+  gnx_prof_scope prof(h, GNX_K_EMBED, 8.0 * N * K + 4.0 * N * H);
   {
     // large batches: the one-hot x gradient product on the MFMA (exact); small ones: LDS-privatised table adds
     const int32_t st = gnx_embed_bwd_mfma(h, idx, N, K, offsets, R, dout, H, dtable);

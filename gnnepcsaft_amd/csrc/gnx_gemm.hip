@@ -1070,9 +1070,11 @@ static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, i
   const size_t lds_bytes = sizeof(float) * (128 * WS_LD + 2 * WS_BM * WS_LD);
   const int cus = h->num_cus > 0 ? h->num_cus : 256;
   const int grid = g.ntiles < cus ? g.ntiles : cus;
-  gnx_prof_scope prof(h, GNX_K_GEMM);
-  hipError_t e;
   const bool split = h->opt[GNX_OPT_GEMM_SPLIT] != 0;  // 0 = exact-fp32 MFMA kernel (A/B switch)
+  const double fl = 2.0 * (double)M * N * s.k;
+  gnx_prof_scope prof(h, GNX_K_GEMM_WS, 4.0 * M * (s.k + N) + ((mask || (flags & GNX_GEMM_ACCUMULATE)) ? 4.0 * M * N : 0.0) +
+                                            4.0 * N * s.k, fl, split ? 6.0 * fl : 0.0);
+  hipError_t e;
   if (split) {
     if (bt)
       e = epi == EPI_MASK    ? ws3_launch_one<true, EPI_MASK>(h, g, grid)
@@ -1210,7 +1212,7 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr) {
     const gnx_gemm_seg& s0 = segs[0];
     dim3 grid((unsigned)gnx_cdiv(M, SM_T), (unsigned)gnx_cdiv(N, SM_T));
-    gnx_prof_scope prof(h, GNX_K_GEMM);
+    gnx_prof_scope prof(h, GNX_K_GEMM_SMALL, 4.0 * (M * (double)(s0.k + N) + (double)N * s0.k), 2.0 * M * N * s0.k, 0.0);
     if (bt)
       hipLaunchKernelGGL(k_gemm_small<true>, grid, dim3(256), 0, h->stream, s0.a, s0.lda, s0.b, s0.ldb, (int)M, (int)N,
                          (int)s0.k, bias, C, ldc, (flags & GNX_GEMM_RELU) ? 1 : 0, (flags & GNX_GEMM_ACCUMULATE) ? 1 : 0);
@@ -1262,7 +1264,6 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     if (g3 > slots) g3 = slots;
   }
   const dim3 grid3(g3);
-  gnx_prof_scope prof(h, GNX_K_GEMM);
   bool vec = h->opt[GNX_OPT_GEMM_VEC] != 0;
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
@@ -1276,6 +1277,11 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     return GNX_E_WORKSPACE;
   }
   GNX_CHECK_ARG(!split || aligned16(ws), "gnx_gemm: workspace must be 16-byte aligned");
+  double ktot = 0.0;
+  for (int q = 0; q < nseg; ++q) ktot += g.seg[q].k;
+  const double fl = 2.0 * (double)M * N * ktot;
+  gnx_prof_scope prof(h, GNX_K_GEMM_TILED, 4.0 * M * (ktot + N) + ((mask || (flags & GNX_GEMM_ACCUMULATE)) ? 4.0 * M * N : 0.0) +
+                                               4.0 * N * ktot * (num_classes > 0 ? num_classes : 1), fl, split ? 6.0 * fl : 0.0);
   if (split) {
     split_args sa;
     for (int q = 0; q < MAX_SEGS; ++q) sa.seg[q] = g.seg[q];
@@ -1831,11 +1837,13 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.nchunks = nchunks;
   g.dw_cls_stride = dw_cls_stride;
   dim3 grid((unsigned)(chunk_info ? max_chunks : gnx_cdiv(M, rows)), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
-  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   bool vec = g.vec_x && g.vec_y && (N % 4 == 0) && (K % 4 == 0);
   if (h->opt[GNX_OPT_WGRAD_VEC] == 0) vec = false;
   const bool offs32 = (uint64_t)M * (uint64_t)lddc < (1ull << 32) && (uint64_t)M * (uint64_t)lda < (1ull << 32);
-  if (wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32)) {
+  const bool wsplit = wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32);
+  const double wfl = 2.0 * (double)M * N * K;
+  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD, 4.0 * M * ((double)N + K) + 4.0 * N * K, wfl, wsplit ? 6.0 * wfl : 0.0);
+  if (wsplit) {
     if (chunk_info)
       hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
     else
@@ -1997,9 +2005,14 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
   for (int i = nprob; i < WGRAD_MAX_BATCH; ++i) b.wg_off[i] = off;
   b.nprob = nprob;
   dim3 grid((unsigned)off);
-  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD);
   bool any_rs = false;
   for (int i = 0; i < nprob; ++i) any_rs = any_rs || probs[i].rowscale != nullptr;
+  double wby = 0.0, wfl = 0.0;
+  for (int i = 0; i < nprob; ++i) {
+    wby += 4.0 * probs[i].M * ((double)probs[i].N + probs[i].K) + 4.0 * probs[i].N * probs[i].K;
+    wfl += 2.0 * (double)probs[i].M * probs[i].N * probs[i].K;
+  }
+  gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD_BATCHED, wby, wfl, wgrad_split_enabled(h, maxM, any_rs) ? 6.0 * wfl : 0.0);
   if (wgrad_split_enabled(h, maxM, any_rs))
     hipLaunchKernelGGL(k_gemm_wgrad3_batched, grid, dim3(256), 0, h->stream, b);
   else

@@ -254,7 +254,7 @@ extern "C" int32_t gnx_batchnorm_fwd(gnx_handle* h, const float* x, int64_t M, i
   float* ab = reinterpret_cast<float*>(ws);
   float* part = ab + 4 * (size_t)H;
   int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
-  gnx_prof_scope prof(h, GNX_K_BN_FWD);
+  gnx_prof_scope prof(h, GNX_K_BN_FWD, (training ? 12.0 : 8.0) * M * H);  // statistics pass + read x, write y
   if (training) {
     if (H % 4 == 0)
       hipLaunchKernelGGL(k_bn_partial_v4, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 128)), dim3(256), 0, h->stream, x,
@@ -358,7 +358,7 @@ extern "C" int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float
   float* coef = reinterpret_cast<float*>(ws);
   float* part = coef + 4 * (size_t)H;
   int64_t chunks = gnx_cdiv(M, BN_ROWS_PER_BLOCK);
-  gnx_prof_scope prof(h, GNX_K_BN_BWD);
+  gnx_prof_scope prof(h, GNX_K_BN_BWD, 28.0 * M * H);  // two passes over dy, x, y + write dx
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_bn_bwd_partial_v4, dim3((unsigned)chunks, (unsigned)gnx_cdiv(H, 128)), dim3(256), 0, h->stream,
                        dy, x, y, M, (int)H, save_mean, save_rstd, (int)relu, part);

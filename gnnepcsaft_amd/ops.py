@@ -628,7 +628,7 @@ def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tens
 
 def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:
     A = torch.empty(g.N, T * 4 * F, dtype=torch.float32, device=m.device)
-    check(_lib.load().gnx_pna_aggregate_fwd(handle(m.device), m.data_ptr(), g.rowptr.data_ptr(), g.N, T, F,
+    check(_lib.load().gnx_pna_aggregate_fwd(handle(m.device), m.data_ptr(), g.rowptr.data_ptr(), g.N, g.E, T, F,
                                             A.data_ptr()))
     return A
 
@@ -636,14 +636,14 @@ def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Te
 def pna_aggregate_bwd(dA: torch.Tensor, m: torch.Tensor, A: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:
     dm = torch.empty_like(m)
     check(_lib.load().gnx_pna_aggregate_bwd(handle(m.device), dA.data_ptr(), m.data_ptr(), A.data_ptr(),
-                                            g.rowptr.data_ptr(), g.N, T, F, dm.data_ptr()))
+                                            g.rowptr.data_ptr(), g.N, g.E, T, F, dm.data_ptr()))
     return dm
 
 
 def gine_aggregate_fwd(x: torch.Tensor, Le: torch.Tensor, g: GraphPack, eps: float) -> torch.Tensor:
     out = torch.empty_like(x)
     check(_lib.load().gnx_gine_aggregate_fwd(handle(x.device), x.data_ptr(), Le.data_ptr(), g.rowptr.data_ptr(),
-                                             g.src.data_ptr(), g.code.data_ptr(), g.N, x.size(1), float(eps),
+                                             g.src.data_ptr(), g.code.data_ptr(), g.N, g.E, x.size(1), float(eps),
                                              out.data_ptr()))
     return out
 
@@ -746,10 +746,18 @@ def prof_begin(device: torch.device, kernel_ids: Sequence[int]) -> None:
 
 
 def prof_read(device: torch.device, kernel_id: int) -> Tuple[int, float]:
-    """(launches, total milliseconds) of one kernel id since prof_begin; synchronises."""
+    """(launches, total milliseconds) of one kernel group since prof_begin; synchronises."""
+    d = prof_read_work(device, kernel_id)
+    return d["launches"], d["ms"]
+
+
+def prof_read_work(device: torch.device, kernel_id: int) -> dict:
+    """launches, total ms, algorithmic bytes, algorithmic FLOPs and executed bf16-MFMA FLOPs of one kernel group."""
     n, ms = C.c_int64(0), C.c_double(0.0)
-    check(_lib.load().gnx_prof_read(handle(device), kernel_id, C.byref(n), C.byref(ms)))
-    return n.value, ms.value
+    by, fl, mf = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    check(_lib.load().gnx_prof_read(handle(device), kernel_id, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl),
+                                    C.byref(mf)))
+    return {"launches": n.value, "ms": ms.value, "bytes": by.value, "flops": fl.value, "mfma_bf16_flops": mf.value}
 
 
 def prof_end(device: torch.device) -> None:

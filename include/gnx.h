@@ -65,26 +65,35 @@ int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
 
 /* ---- profiling hook (bench.py's live per-kernel timing; HIP events on the handle's stream) ------------------- */
-/* kernel ids */
+/* kernel ids (groups of kernels with one roofline) */
 enum {
   GNX_K_NONE = 0,
-  GNX_K_PNA_AGG_FWD = 1,
+  GNX_K_PNA_AGG_FWD = 1,        /* scatter-aggregate forward (the metric's roofline kernel) */
   GNX_K_PNA_AGG_BWD = 2,
-  GNX_K_GEMM = 3,
-  GNX_K_GEMM_WGRAD = 4,
+  GNX_K_GEMM_WS = 3,            /* weights-stationary products (K, N <= 128) */
+  GNX_K_GEMM_WGRAD = 4,         /* single / per-degree-class weight gradients */
   GNX_K_GINE_AGG_FWD = 5,
   GNX_K_GINE_AGG_BWD = 6,
   GNX_K_EDGE_COMBINE_FWD = 7,
   GNX_K_EDGE_COMBINE_BWD = 8,
   GNX_K_BN_FWD = 9,
   GNX_K_BN_BWD = 10,
-  GNX_K_COUNT = 11
+  GNX_K_GEMM_TILED = 11,        /* tiled multi-segment / degree-class-grouped products (incl. their weight split) */
+  GNX_K_GEMM_SMALL = 12,        /* M <= 256 products (60-row bond-table chain, merged H x H weights) */
+  GNX_K_GEMM_WGRAD_BATCHED = 13,/* a layer's weight gradients in one launch */
+  GNX_K_KEY_SEGMENT_SUM = 14,   /* bond-table gradient through the inverted index */
+  GNX_K_EMBED = 15,             /* embedding sums, forward and backward */
+  GNX_K_COUNT = 16
 };
 /* start recording a HIP event pair around every launch of the kernels whose id bit is set in kernel_mask
  * (bit k = GNX_K_* id k).  Events go on the handle's stream, i.e. the stream the kernels run on. */
 int32_t gnx_prof_begin(gnx_handle* h, uint32_t kernel_mask);
-/* synchronise the stream; #launches of kernel `kid` seen since gnx_prof_begin and their summed duration (ms). */
-int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms);
+/* synchronise the stream; #launches of kernel group `kid` seen since gnx_prof_begin, their summed duration (ms), and
+ * the sums of what the launches were given to do: ALGORITHMIC bytes (operands read + results written once, fp32 /
+ * int32), algorithmic FLOPs (2 M N K of the products) and the bf16-MFMA FLOPs actually executed (6 x the
+ * algorithmic ones on the split-operand kernels, 0 on fp32-MFMA kernels).  Any of the three may be NULL. */
+int32_t gnx_prof_read(gnx_handle* h, int32_t kid, int64_t* launches, double* total_ms, double* alg_bytes,
+                      double* alg_flops, double* mfma_bf16_flops);
 /* stop recording and drop the recorded events. */
 int32_t gnx_prof_end(gnx_handle* h);
 
@@ -245,8 +254,8 @@ int32_t gnx_key_segment_sum(gnx_handle* h, const float* g, const int32_t* pos, c
  * (aggregator list ref: train/models.py:443).  m fp32[E, T*F] in CSR order, rowptr int32[N+1].
  * A fp32[N, T, 4F]: per tower [mean || min || max || std].  Empty rows -> 0.  mean = (sequential sum in CSR order)/max(d,1);
  * std = sqrt(max(mean(x*x) - mean^2, 1e-5)) masked to 0 when <= sqrt(1e-5). */
-int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int32_t T, int32_t F,
-                              float* A);
+int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowptr, int64_t N, int64_t E, int32_t T,
+                              int32_t F, float* A);
 /* dm[E,T*F] from dA[N,T,4F]; min/max gradients split evenly over ties (scatter_reduce amin/amax backward);
  * std gradient 0 where the forward masked (the mask decision is the forward's, bit for bit).  Where it is not masked
  * the gradient is dstd (m - mean) / (n std): with GNX_OPT_STD_BWD_CENTERED (default) `std` is re-evaluated as
@@ -254,12 +263,13 @@ int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowp
  * cancellation error (~ eps mean(x^2) / (2 var) relative, up to 3e-5 just above the mask) the CPU path carries into
  * its gradient; 0 = divide by the forward's value like the CPU path does. */
 int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A, const int32_t* rowptr,
-                              int64_t N, int32_t T, int32_t F, float* dm);
+                              int64_t N, int64_t E, int32_t T, int32_t F, float* dm);
 
 /* ---- GINE message + sum aggregate (fused gather, no materialised messages) --------------------------------- */
 /* [3P] GINEConv (ref: train/models.py:529-538): out[i,:] = (1+eps) x[i,:] + sum_{p in row i} relu(x[src[p],:] + Le[code[p],:]) */
 int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const float* Le, const int32_t* rowptr,
-                               const int32_t* src, const int32_t* code, int64_t N, int32_t H, float eps, float* out);
+                               const int32_t* src, const int32_t* code, int64_t N, int64_t E, int32_t H, float eps,
+                               float* out);
 /* dx[j,:] = (1+eps) dout[j,:] + sum_{p in cpos(j)} dout[dst[p],:] * (x[j,:] + Le[code[p],:] > 0);
  * dLe[R,H] (optional) += sum_p [code[p]==r] dout[dst[p],:] * (x[src[p],:] + Le[r,:] > 0); code_pos (optional) =
  * CSR positions stably grouped by code (gnx_group_by_small_key): register sums per key run instead of LDS atomics. */
