@@ -99,6 +99,7 @@ SIGNATURES = {
     "gnx_batchnorm_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _vp, _vp, _vp,
                                  _vp, _sz]),
     "gnx_batchnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz]),
+    "gnx_dropout": (_i32, [_vp, _vp, _i64, _f32, C.c_uint64, C.c_uint64, _vp]),
     "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gnx_adamw_amsgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "gnx_sgd": (_i32, [_vp, _vp, _vp, _i64, _f32]),

@@ -225,6 +225,59 @@ extern "C" int32_t gnx_scale(gnx_handle* h, float* p, int64_t n, float v) {
   return GNX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dropout (reference: torch.nn.Dropout(p) in front of every conv, train/models.py:177,209; p = 0.25 in
+// configs/pna_msigmae_7.py:40).  Counter-based Philox4x32-10: element i of a call is decided by the 128-bit counter
+// (i / 4, offset) under the 64-bit key `seed` -- no state, so the backward pass RECOMPUTES the mask from
+// (seed, offset) instead of storing it, and forward / backward agree by construction.  One thread = 4 consecutive
+// elements = one Philox block.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0;
+    c[1] = lo1;
+    c[2] = n2;
+    c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dropout(const float* __restrict__ x, int64_t n, float p, float scale,
+                                                 uint64_t seed, uint64_t offset, float* __restrict__ y) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // block of 4 elements
+  const int64_t i0 = q * 4;
+  if (i0 >= n) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float v[4];
+  if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i0);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((float)(c[j] >> 8) * 5.9604644775390625e-8f >= p) ? v[j] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(y + i0) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    for (int j = 0; j < 4 && i0 + j < n; ++j)
+      y[i0 + j] = ((float)(c[j] >> 8) * 5.9604644775390625e-8f >= p) ? x[i0 + j] * scale : 0.f;
+  }
+}
+
+extern "C" int32_t gnx_dropout(gnx_handle* h, const float* x, int64_t n, float p, uint64_t seed, uint64_t offset,
+                               float* y) {
+  GNX_CHECK_ARG(h && ((x && y) || n == 0) && n >= 0, "gnx_dropout: bad argument");
+  GNX_CHECK_ARG(p >= 0.f && p < 1.f, "gnx_dropout: p=%g not in [0,1)", (double)p);
+  if (n == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_dropout, dim3((unsigned)gnx_cdiv(gnx_cdiv(n, 4), 256)), dim3(256), 0, h->stream, x, n, p,
+                     1.0f / (1.0f - p), seed, offset, y);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
 __global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;

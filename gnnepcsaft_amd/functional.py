@@ -120,6 +120,21 @@ class EmbedSumFn(torch.autograd.Function):
         return (None, None) + tuple(dtable[offs[k]:offs[k + 1]] for k in range(len(sinks)))
 
 
+class DropoutFn(torch.autograd.Function):
+    """torch.nn.Dropout(p) in training mode (reference models.py:177, 209): y = x * Bernoulli(1 - p) / (1 - p).  The
+    mask is a pure function of (seed, offset) (gnx_dropout, Philox4x32-10), so backward recomputes it."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        ctx.key = (float(p), int(seed), int(offset))
+        return ops.dropout(x, p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.key
+        return ops.dropout(dy, p, seed, offset), None, None, None
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b (torch.nn.Linear / PyG Linear; readout MLP models.py:186-194)."""
 

@@ -33,6 +33,33 @@ class ReLU(Module):
         raise RuntimeError("standalone ReLU is fused into the producing kernel on this path")
 
 
+class Dropout(Module):
+    """torch.nn.Dropout(p) on the HIP path (reference models.py:177, 209).  Identity in eval mode and for p = 0 (no
+    launch).  In training mode every call draws a fresh mask from a counter-based generator: key = ``seed`` (taken from
+    torch's global seed at construction unless given, so ``torch.manual_seed`` makes runs repeatable), counter = an
+    offset that advances by one per call; checkpointing ``(seed, calls)`` resumes the stream exactly.  No parameters
+    or buffers: state-dict compatible with the reference's ``dropout`` attribute."""
+
+    def __init__(self, p: float = 0.5, seed: Optional[int] = None):
+        super().__init__()
+        if p < 0.0 or p > 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {p}")
+        if p == 1.0:
+            raise ValueError("native Dropout implements p in [0, 1) (the reference's configs use 0 and 0.25)")
+        self.p = float(p)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        self.calls = 0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training or self.p == 0.0:
+            return x
+        self.calls += 1
+        return Fn.DropoutFn.apply(x, self.p, self.seed, self.calls)
+
+    def extra_repr(self) -> str:
+        return f"p={self.p}"
+
+
 class _Encoder(Module):
     dims: Sequence[int] = ()
     list_name = ""

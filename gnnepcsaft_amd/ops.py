@@ -717,6 +717,15 @@ def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu: bool, dgamma=None, dbeta=No
     return dx, dgamma, dbeta
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
+    """x * mask / (1 - p), mask from Philox keyed by (seed, offset); the same call on a gradient is the backward."""
+    x = _f32(x, "x").contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().gnx_dropout(handle(x.device), x.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                                  int(offset) & (2 ** 64 - 1), y.data_ptr()))
+    return y
+
+
 def huber_ape(pred: torch.Tensor, target: torch.Tensor, delta: float, need_grad: bool):
     pred = _f32(pred, "pred").contiguous()
     target = _f32(target, "target").contiguous()

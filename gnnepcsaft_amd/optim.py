@@ -42,9 +42,32 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):  # pylint: disable=arguments-differ
         self.grads.zero_grad()  # keeps p.grad as views of the flat gradient buffer
 
+    # ---- checkpointing: plain tensors and numbers only, so ``torch.load(weights_only=True)`` reads it back -----------
+    _FLAT_STATE = ()
+
+    def flat_state_dict(self) -> dict:
+        out = {"kind": type(self).__name__, "step": int(self._step), "numel": int(self.flat_param.numel()),
+               "param_groups": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items() if k != "params"}
+                                for g in self.param_groups]}
+        for name in self._FLAT_STATE:
+            out[name] = getattr(self, name).detach().cpu().clone()
+        return out
+
+    def load_flat_state_dict(self, state: dict) -> None:
+        if state.get("kind") != type(self).__name__ or int(state.get("numel", -1)) != self.flat_param.numel():
+            raise ValueError(f"optimizer state of {state.get('kind')} with {state.get('numel')} elements does not fit "
+                             f"{type(self).__name__} with {self.flat_param.numel()}")
+        self._step = int(state["step"])
+        for g, sg in zip(self.param_groups, state["param_groups"]):
+            for k, v in sg.items():
+                g[k] = tuple(v) if k == "betas" else v
+        for name in self._FLAT_STATE:
+            getattr(self, name).copy_(state[name].to(self.flat_param.device))
+
 
 class FusedAdamW(_FlatOptimizer):
     """torch.optim.AdamW(lr, weight_decay, amsgrad=True, eps=1e-5) semantics, one kernel per step."""
+    _FLAT_STATE = ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")
 
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-5, weight_decay=1e-2, grads=None):
         super().__init__(module, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True), grads)

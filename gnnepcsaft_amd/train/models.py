@@ -11,7 +11,7 @@ import math
 from typing import Any, Optional, Union
 
 import torch
-from torch.nn import Dropout, ModuleList, Sequential
+from torch.nn import ModuleList, Sequential
 from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
 
 from .. import functional as Fn
@@ -128,7 +128,7 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
         self.num_para = P
         self.lower_bounds, self.upper_bounds = torch.tensor(_LOWER), torch.tensor(_UPPER)
         self.node_embed, self.edge_embed = gnn.AtomEncoder(H), gnn.BondEncoder(H)
-        self.dropout = Dropout(p=config["dropout"])
+        self.dropout = gnn.Dropout(p=config["dropout"])
         self.global_pool_type = config["global_pool"]
         self.global_pool = get_global_pool(config)
         depth = config["propagation_depth"]

@@ -34,8 +34,19 @@ class DataLoader:
         order = np.arange(len(self.dataset))
         if self.shuffle:
             self._rng.shuffle(order)
+        self.last_order = order
         for i in range(0, len(order), self.batch_size):
             yield Batch.from_data_list([self.dataset[j] for j in order[i:i + self.batch_size]])
+
+    def rng_state(self) -> dict:
+        """The shuffle generator's state as plain ints (PCG64: 128-bit state and increment)."""
+        st = self._rng.bit_generator.state
+        return {"state": int(st["state"]["state"]), "inc": int(st["state"]["inc"]), "has_uint32": int(st["has_uint32"]),
+                "uinteger": int(st["uinteger"])}
+
+    def set_rng_state(self, st: dict) -> None:
+        self._rng.bit_generator.state = {"bit_generator": "PCG64", "state": {"state": int(st["state"]), "inc": int(st["inc"])},
+                                         "has_uint32": int(st["has_uint32"]), "uinteger": int(st["uinteger"])}
 
 
 # Classes a Lightning ``.ckpt`` of the reference pickles next to its ``state_dict``: ``save_hyperparameters(config)``
@@ -99,12 +110,38 @@ class Trainer:
         self.current_epoch = 0
         self.logged: List[dict] = []
         self.validation_results: List[dict] = []
+        self._opt = self._sched = self._loader = None
+        self._batch_in_epoch = 0
+        self._epoch_rng = None
 
     # ------------------------------------------------------------------------------------------------------------
     def save_checkpoint(self, model, path: str) -> None:
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": self.current_epoch,
-                    "hyper_parameters": {"config": dict(model.config)}}, path)
+        """Weights AND everything a resumed run needs to continue exactly where this one stopped (Lightning's
+        ``ckpt_path`` resume, reference train.py:105-115): optimizer moments / step count / learning rate, LR-scheduler
+        state, epoch, position inside the epoch with the shuffle generator's state at the epoch's start, and the
+        dropout counter.  Tensors, numbers, lists and dicts only: ``read_checkpoint`` loads it with
+        ``weights_only=True``.  Under data parallelism rank 0 writes and everybody waits for it."""
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not ddp or dist.get_rank() == 0:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            ckpt = {"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                    "global_step": self.global_step, "epoch": self.current_epoch,
+                    "hyper_parameters": {"config": dict(model.config)}, "loops": {
+                        "batch_in_epoch": self._batch_in_epoch, "loader_rng_at_epoch_start": self._epoch_rng,
+                        "loader_rng_now": self._loader.rng_state() if hasattr(self._loader, "rng_state") else None}}
+            if self._opt is not None:
+                ckpt["optimizer_states"] = [self._opt.flat_state_dict() if hasattr(self._opt, "flat_state_dict")
+                                            else self._opt.state_dict()]
+                ckpt["lr_schedulers"] = [self._sched.state_dict()]
+            drop = getattr(model.model, "dropout", None)
+            if drop is not None and hasattr(drop, "calls"):
+                ckpt["dropout"] = {"seed": int(drop.seed), "calls": int(drop.calls)}
+            tmp = path + ".tmp"
+            torch.save(ckpt, tmp)
+            os.replace(tmp, path)
+        if ddp:
+            dist.barrier()
 
     @staticmethod
     def load_state_dict(model, path: str) -> dict:
@@ -120,20 +157,48 @@ class Trainer:
         model.to(self.device)
         model.train()
         model.trainer = self
+        ckpt = None
         if ckpt_path:
             ckpt = self.load_state_dict(model, ckpt_path)
             self.global_step = int(ckpt.get("global_step", 0))
+            self.current_epoch = int(ckpt.get("epoch", 0))
         dp.broadcast_parameters(model)
         grads = dp.FlatGradAllReduce(model)
         oc = configure_fused_optimizers(model, grads) if self.fused_optimizer else model.configure_optimizers()
         opt = oc["optimizer"]
         sched, freq = oc["lr_scheduler"]["scheduler"], int(oc["lr_scheduler"].get("frequency", 1))
+        self._opt, self._sched, self._loader = opt, sched, train_dataloaders
+        skip = 0
+        if ckpt is not None:  # the rest of the training state (absent in weights-only / foreign checkpoints)
+            if ckpt.get("optimizer_states"):
+                st = ckpt["optimizer_states"][0]
+                opt.load_flat_state_dict(st) if hasattr(opt, "load_flat_state_dict") and "kind" in st else opt.load_state_dict(st)
+            if ckpt.get("lr_schedulers"):
+                sched.load_state_dict(ckpt["lr_schedulers"][0])
+                for g, lr in zip(opt.param_groups, sched.get_last_lr()):
+                    g["lr"] = lr
+            loops = ckpt.get("loops") or {}
+            skip = int(loops.get("batch_in_epoch", 0))
+            if hasattr(train_dataloaders, "set_rng_state"):
+                # mid-epoch: replay the interrupted epoch's shuffle and skip what was consumed; else continue the stream
+                st = loops.get("loader_rng_at_epoch_start") if skip > 0 else loops.get("loader_rng_now")
+                if st is not None:
+                    train_dataloaders.set_rng_state(st)
+            drop = getattr(model.model, "dropout", None)
+            if ckpt.get("dropout") and drop is not None and hasattr(drop, "calls"):
+                drop.seed, drop.calls = int(ckpt["dropout"]["seed"]), int(ckpt["dropout"]["calls"])
         prev_in_place = Fn._GRAD_IN_PLACE  # pylint: disable=protected-access
+        prev_validate = model.model.validate_inputs
         Fn.set_grad_in_place(self.fused_optimizer)
         model.model.validate_inputs = False  # one range check per logging interval instead of one sync per batch
         try:
             while self.max_steps < 0 or self.global_step < self.max_steps:
+                self._epoch_rng = train_dataloaders.rng_state() if hasattr(train_dataloaders, "rng_state") else None
+                self._batch_in_epoch = 0
                 for batch in train_dataloaders:
+                    self._batch_in_epoch += 1
+                    if skip >= self._batch_in_epoch:
+                        continue  # batches of the interrupted epoch that the checkpointed run had already consumed
                     b = batch.to(self.device, non_blocking=True)
                     if self.fused_optimizer:
                         opt.zero_grad()
@@ -155,13 +220,28 @@ class Trainer:
                         self._validate(model, val_dataloaders)
                     if 0 <= self.max_steps <= self.global_step:
                         break
-                self.current_epoch += 1
-                if self.current_epoch % freq == 0:  # "interval": "epoch", "frequency": 10 (models.py:72-73)
-                    sched.step()
-                if self.max_steps < 0:
-                    break  # one epoch when no step budget is given
+                else:
+                    # the epoch ran to its end (no break): epoch bookkeeping + the scheduler's cadence
+                    skip = 0
+                    self._batch_in_epoch = 0
+                    self._epoch_rng = None
+                    self.current_epoch += 1
+                    if self.current_epoch % freq == 0:  # "interval": "epoch", "frequency": 10 (models.py:72-73)
+                        sched.step()
+                    if self.max_steps < 0:
+                        break  # one epoch when no step budget is given
+                    continue
+                # stopped inside an epoch by max_steps
+                if self._batch_in_epoch >= len(train_dataloaders):  # ... exactly at its last batch: the epoch is complete
+                    self._batch_in_epoch = 0
+                    self._epoch_rng = None
+                    self.current_epoch += 1
+                    if self.current_epoch % freq == 0:
+                        sched.step()
+                break
         finally:
             Fn.set_grad_in_place(prev_in_place)
+            model.model.validate_inputs = prev_validate
         ops.check_range(self.device)
         if self.enable_checkpointing and self.default_root_dir:
             self.save_checkpoint(model, os.path.join(self.default_root_dir, "last.ckpt"))

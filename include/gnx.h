@@ -299,6 +299,13 @@ int32_t gnx_batchnorm_bwd(gnx_handle* h, const float* dy, const float* x, const 
                           const float* gamma, const float* save_mean, const float* save_rstd, int32_t relu,
                           float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes);
 
+/* ---- dropout (ref: train/models.py:177, 209; p = 0.25 in configs/pna_msigmae_7.py:40) --------------------------- */
+/* y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) decided by Philox4x32-10 on the counter (i / 4, offset) under the
+ * key `seed` (uniform u in [0,1) from 24 bits; keep iff u >= p).  Stateless: calling it again with the same
+ * (seed, offset) on the upstream gradient IS the backward pass (the mask is recomputed, never stored).  In place
+ * (y == x) is allowed.  torch's RNG stream cannot be reproduced; parity for p > 0 is statistical. */
+int32_t gnx_dropout(gnx_handle* h, const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, float* y);
+
 /* ---- loss: APE-Huber (ref: train/models.py:89-91) + MAPE metric (:92) ---------------------------------------- */
 /* out[0] = mean huber((pred-t)/t, delta), out[1] = mean |pred-t|/max(|t|,1.17e-6); dpred (optional) = d out[0]/d pred. */
 int32_t gnx_huber_ape(gnx_handle* h, const float* pred, const float* target, int64_t count, float delta, float* out2,

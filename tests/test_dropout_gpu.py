@@ -1,0 +1,109 @@
+"""Dropout p > 0 on the HIP path (reference: torch.nn.Dropout in front of every conv, train/models.py:177, 209; p = 0.25
+in configs/pna_msigmae_7.py:40).  torch's RNG stream cannot be reproduced, so the kernel is tested (a) statistically
+(keep rate, 1/(1-p) scale, eval = identity, determinism in (seed, call)), (b) for forward/backward mask agreement, and
+(c) end to end: the masks the kernel drew are replayed inside the CPU oracle and the whole model must then agree."""
+import copy
+import math
+
+import pytest
+import torch
+
+from oracle import pyg_restatement as O
+from tests.parity_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("p", [0.25, 0.5, 0.1])
+def test_dropout_statistics_scale_and_backward_mask(gpu_device, p):
+    from gnnepcsaft_amd import nn as gnn
+    torch.manual_seed(5)
+    n, H = 20000, 128
+    x = (torch.randn(n, H, device=gpu_device) + 3.0).requires_grad_(True)  # no zeros: the mask is visible in y
+    d = gnn.Dropout(p, seed=1234).to(gpu_device).train()
+    y = d(x)
+    keep = y != 0
+    rate = float(keep.float().mean())
+    sigma = math.sqrt(p * (1 - p) / (n * H))
+    assert abs(rate - (1 - p)) <= 5 * sigma, (rate, 1 - p, sigma)
+    # per-row and per-column keep rates are unbiased too (no structure along either axis)
+    assert float((keep.float().mean(0) - (1 - p)).abs().max()) <= 6 * math.sqrt(p * (1 - p) / n)
+    assert float((keep.float().mean(1) - (1 - p)).abs().max()) <= 6 * math.sqrt(p * (1 - p) / H)
+    scale = torch.tensor(1.0, dtype=torch.float32) / (1.0 - torch.tensor(p, dtype=torch.float32))
+    assert torch.equal(y[keep], (x.detach() * scale.to(gpu_device))[keep]), "kept values = x * (1 / (1 - p)) in fp32"
+    dy = torch.randn(n, H, device=gpu_device) + 5.0
+    y.backward(dy)
+    assert torch.equal(x.grad != 0, keep), "backward recomputes the forward's mask"
+    assert torch.equal(x.grad[keep], (dy * scale.to(gpu_device))[keep])
+    # a second call draws another mask; the same (seed, call index) redraws the same one
+    y2 = d(x.detach())
+    assert not torch.equal(y2 != 0, keep)
+    d2 = gnn.Dropout(p, seed=1234).to(gpu_device).train()
+    assert torch.equal(d2(x.detach()), y.detach())
+    d2.calls = 1
+    assert torch.equal(d2(x.detach()), y2)
+
+
+def test_dropout_identity_in_eval_and_for_p0(gpu_device):
+    from gnnepcsaft_amd import nn as gnn
+    x = torch.randn(100, 32, device=gpu_device)
+    assert gnn.Dropout(0.25).eval()(x) is x
+    assert gnn.Dropout(0.0).train()(x) is x
+    with pytest.raises(ValueError):
+        gnn.Dropout(1.5)
+    odd = torch.randn(1001, device=gpu_device)  # length not a multiple of 4, unaligned tail
+    y = gnn.Dropout(0.5, seed=7).train()(odd)
+    assert y.shape == odd.shape and 0.3 < float((y != 0).float().mean()) < 0.7
+
+
+class _ReplayDropout(torch.nn.Module):
+    """Stands in for the oracle's torch.nn.Dropout: multiplies by the masks the HIP kernel drew, in call order."""
+
+    def __init__(self, masks, p):
+        super().__init__()
+        self.masks, self.p, self.i = masks, p, 0
+
+    def forward(self, x):
+        m = self.masks[self.i].to(x.dtype)
+        self.i += 1
+        return x * m * (1.0 / (1.0 - self.p))
+
+
+@pytest.mark.parametrize("conv,kw", [("GINE", dict(hidden_dim=64, propagation_depth=3)),
+                                     ("PNA", dict(hidden_dim=32, pre_layers=1, post_layers=1, propagation_depth=2))])
+def test_model_with_dropout_matches_oracle_on_the_same_masks(gpu_device, conv, kw):
+    """Whole model, training mode, p = 0.25 (configs/pna_msigmae_7.py:40): the HIP path draws the masks; the CPU oracle
+    replays exactly those masks; predictions, loss and gradients must agree like in the p = 0 model tests."""
+    from gnnepcsaft_amd import functional as Fn, ops
+    from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
+    from gnnepcsaft_amd.train.models import GNNePCSAFT
+    cfg = default_config(2)
+    cfg.update(conv=conv, dropout=0.25, **kw)
+    batch = synthetic_batch(32, 3 if conv == "GINE" else 1)
+    cfg["deg"] = calc_deg(batch)
+    torch.manual_seed(0)
+    oracle = O.GNNePCSAFT(cfg).train()
+    native = GNNePCSAFT(cfg)
+    native.load_state_dict(oracle.state_dict(), strict=True)
+    native.train().to(gpu_device)
+    assert native.dropout.p == 0.25 and native.dropout.calls == 0
+    b = batch.to(gpu_device)
+    pred = native(b.x, b.edge_index, b.edge_attr, b.batch)
+    loss, _ = Fn.HuberAPEFn.apply(pred, b.para, 0.01)
+    loss.backward()
+    L, N, H = cfg["propagation_depth"], batch.x.size(0), cfg["hidden_dim"]
+    assert native.dropout.calls == L
+    ones = torch.ones(N, H, device=gpu_device)
+    masks = [(ops.dropout(ones, 0.25, native.dropout.seed, call) != 0).cpu() for call in range(1, L + 1)]
+    assert all(0.70 < float(m.float().mean()) < 0.80 for m in masks)
+    oracle.dropout = _ReplayDropout(masks, 0.25)
+    pred_o = oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    loss_o = O.ape_huber_loss(pred_o, batch.para)
+    loss_o.backward()
+    assert rel_err(loss, loss_o) <= 1e-5
+    assert rel_err(pred, pred_o) <= 1e-5
+    go = {n: p.grad for n, p in oracle.named_parameters()}
+    gn = {n: p.grad for n, p in native.named_parameters()}
+    num = sum(float(((gn[n].cpu().double() - go[n].double()) ** 2).sum()) for n in go)
+    den = sum(float((go[n].double() ** 2).sum()) for n in go)
+    assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
