@@ -110,6 +110,9 @@ SIGNATURES = {
     "gnx_side_begin": (_i32, [_vp]),
     "gnx_side_end": (_i32, [_vp]),
     "gnx_side_join": (_i32, [_vp]),
+    "gnx_side_stream_n": (_i32, [_vp, _i32, C.POINTER(_vp)]),
+    "gnx_side_begin_n": (_i32, [_vp, _i32]),
+    "gnx_side_join_n": (_i32, [_vp, _i32]),
     "gnx_clip_rows": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 }
 

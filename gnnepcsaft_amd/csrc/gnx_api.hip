@@ -70,9 +70,11 @@ extern "C" int32_t gnx_destroy(gnx_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   (void)hipFree(h->d_flag);
   (void)hipFree(h->d_scratch);
-  if (h->side_fork) (void)hipEventDestroy(h->side_fork);
-  if (h->side_done) (void)hipEventDestroy(h->side_done);
-  if (h->side) (void)hipStreamDestroy(h->side);
+  for (int i = 0; i < gnx_handle::kSideStreams; ++i) {
+    if (h->side_fork[i]) (void)hipEventDestroy(h->side_fork[i]);
+    if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
+    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+  }
   delete h;
   return GNX_OK;
 }
@@ -84,34 +86,42 @@ extern "C" int32_t gnx_set_stream(gnx_handle* h, void* hip_stream) {
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_side_begin(gnx_handle* h) {
-  GNX_CHECK_ARG(h != nullptr, "gnx_side_begin: handle is NULL");
-  GNX_CHECK_ARG(!h->on_side, "gnx_side_begin: already on the side stream");
-  if (h->side == nullptr) {
+static int32_t side_ensure(gnx_handle* h, int which) {
+  GNX_CHECK_ARG(h != nullptr, "gnx_side_*: handle is NULL");
+  GNX_CHECK_ARG(which >= 0 && which < gnx_handle::kSideStreams, "gnx_side_*: stream %d not in [0,%d)", which,
+                gnx_handle::kSideStreams);
+  if (h->side[which] == nullptr) {
     GNX_HIP(hipSetDevice(h->device));
-    GNX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    GNX_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
-    GNX_HIP(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+    GNX_HIP(hipStreamCreateWithFlags(&h->side[which], hipStreamNonBlocking));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_fork[which], hipEventDisableTiming));
+    GNX_HIP(hipEventCreateWithFlags(&h->side_done[which], hipEventDisableTiming));
   }
-  GNX_HIP(hipEventRecord(h->side_fork, h->stream));
-  GNX_HIP(hipStreamWaitEvent(h->side, h->side_fork, 0));
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_side_begin_n(gnx_handle* h, int32_t which) {
+  const int32_t st = side_ensure(h, which);
+  if (st != GNX_OK) return st;
+  GNX_CHECK_ARG(!h->on_side, "gnx_side_begin: already on a side stream");
+  GNX_HIP(hipEventRecord(h->side_fork[which], h->stream));
+  GNX_HIP(hipStreamWaitEvent(h->side[which], h->side_fork[which], 0));
   h->main_saved = h->stream;
-  h->stream = h->side;
+  h->stream = h->side[which];
   h->on_side = true;
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_side_stream(gnx_handle* h, void** hip_stream) {
-  GNX_CHECK_ARG(h != nullptr && hip_stream != nullptr, "gnx_side_stream: NULL argument");
-  if (h->side == nullptr) {
-    GNX_HIP(hipSetDevice(h->device));
-    GNX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    GNX_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
-    GNX_HIP(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
-  }
-  *hip_stream = reinterpret_cast<void*>(h->side);
+extern "C" int32_t gnx_side_begin(gnx_handle* h) { return gnx_side_begin_n(h, 0); }
+
+extern "C" int32_t gnx_side_stream_n(gnx_handle* h, int32_t which, void** hip_stream) {
+  GNX_CHECK_ARG(hip_stream != nullptr, "gnx_side_stream: NULL argument");
+  const int32_t st = side_ensure(h, which);
+  if (st != GNX_OK) return st;
+  *hip_stream = reinterpret_cast<void*>(h->side[which]);
   return GNX_OK;
 }
+
+extern "C" int32_t gnx_side_stream(gnx_handle* h, void** hip_stream) { return gnx_side_stream_n(h, 0, hip_stream); }
 
 extern "C" int32_t gnx_side_end(gnx_handle* h) {
   GNX_CHECK_ARG(h != nullptr, "gnx_side_end: handle is NULL");
@@ -122,14 +132,17 @@ extern "C" int32_t gnx_side_end(gnx_handle* h) {
   return GNX_OK;
 }
 
-extern "C" int32_t gnx_side_join(gnx_handle* h) {
+extern "C" int32_t gnx_side_join_n(gnx_handle* h, int32_t which) {
   GNX_CHECK_ARG(h != nullptr, "gnx_side_join: handle is NULL");
+  GNX_CHECK_ARG(which >= 0 && which < gnx_handle::kSideStreams, "gnx_side_join: bad stream %d", which);
   GNX_CHECK_ARG(!h->on_side, "gnx_side_join: between gnx_side_begin and gnx_side_end");
-  if (h->side == nullptr) return GNX_OK;
-  GNX_HIP(hipEventRecord(h->side_done, h->side));
-  GNX_HIP(hipStreamWaitEvent(h->stream, h->side_done, 0));
+  if (h->side[which] == nullptr) return GNX_OK;
+  GNX_HIP(hipEventRecord(h->side_done[which], h->side[which]));
+  GNX_HIP(hipStreamWaitEvent(h->stream, h->side_done[which], 0));
   return GNX_OK;
 }
+
+extern "C" int32_t gnx_side_join(gnx_handle* h) { return gnx_side_join_n(h, 0); }
 
 int32_t gnx_read_flag(gnx_handle* h, int* value) {
   int v = 0;

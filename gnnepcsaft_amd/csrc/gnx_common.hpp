@@ -16,10 +16,11 @@ struct gnx_handle {
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;
   float* d_scratch = nullptr;  // 4 KiB
-  // side stream (gnx_side_begin/end/join): created on first use; `stream` is swapped to it between begin and end
-  hipStream_t side = nullptr;
+  // side streams (gnx_side_begin/end/join): created on first use; `stream` is swapped to one between begin and end
+  static constexpr int kSideStreams = 2;
+  hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipStream_t main_saved = nullptr;
-  hipEvent_t side_fork = nullptr, side_done = nullptr;
+  hipEvent_t side_fork[kSideStreams] = {nullptr, nullptr}, side_done[kSideStreams] = {nullptr, nullptr};
   bool on_side = false;
   // A/B switches (gnx_set_option); initialised ONCE from the GNX_* environment variables in gnx_create
   int opt[GNX_OPT_COUNT] = {};

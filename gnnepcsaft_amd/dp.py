@@ -107,6 +107,9 @@ class FlatGradAllReduce:
         if self.flat.is_cuda and ops.wgrad_stream_enabled():
             if self._side is None:
                 self._side = ops.side_stream(self.flat.device)
+            if ops.second_side_stream_in_use(self.flat.device):
+                # part of a conv layer's gradients (bond-table chain) is produced on side stream 1
+                self._side.wait_stream(ops.side_stream(self.flat.device, 1))
             with torch.cuda.stream(self._side):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

@@ -36,6 +36,20 @@ def prepare_ahead_enabled() -> bool:
     return _PREPARE_AHEAD
 
 
+_BOND_CHAIN_ASIDE = True
+
+
+def set_bond_chain_aside(enabled: bool) -> None:
+    """A/B switch: PNA layers accumulate the bond-embedding gradient into one shared buffer on side stream 1 (default
+    on); off = every layer computes it on the main stream and autograd sums the layers' contributions."""
+    global _BOND_CHAIN_ASIDE
+    _BOND_CHAIN_ASIDE = bool(enabled)
+
+
+def bond_chain_aside_enabled() -> bool:
+    return _BOND_CHAIN_ASIDE
+
+
 def set_degree_classes(enabled: bool) -> None:
     """A/B switch for PNA's per-degree-class post-layer 0 (default on; off = the 4-segment 13F-wide product)."""
     global _USE_DEGREE_CLASSES
@@ -248,6 +262,19 @@ def _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
     return EE, Te, weffs, Wm, bm
 
 
+class BondGradAccumulator:
+    """One [R, H] buffer per model forward into which every conv layer's backward ACCUMULATES its bond-embedding
+    gradient on side stream 1 (in-order there, so the adds never race); only layer 0 -- whose backward runs last --
+    joins that stream and returns the total to autograd.  ``depth`` = number of conv layers sharing the bond table."""
+
+    def __init__(self, R: int, H: int, device, depth: int):
+        self.buf = torch.empty(R, H, dtype=torch.float32, device=device)
+        self.depth = depth
+
+    def first_in_backward(self, layer_index: int) -> bool:
+        return layer_index == self.depth - 1
+
+
 class WeightOnlyAhead:
     """``_pna_weight_only`` issued on the library's side stream (when enabled) so that its ~5 tiny dependent launches
     leave the critical path: the model issues layer l+1's while layer l runs.  ``wait()`` orders the caller's stream
@@ -305,7 +332,8 @@ class PNAConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, BE, pack: GraphPack, cfg, *params):
-        T, F, pre_layers, post_layers, avg_deg_log, prep = cfg
+        T, F, pre_layers, post_layers, avg_deg_log, prep = cfg[:6]
+        ctx.bond_acc, ctx.layer_index = (cfg[6], cfg[7]) if len(cfg) > 6 else (None, 0)
         x = x.contiguous()
         N, H = x.shape
         E, R = pack.E, BE.size(0)
@@ -446,8 +474,7 @@ class PNAConvFn(torch.autograd.Function):
                 ops.queue_wgrad(ge[:, sl[t]], h_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
                 ops.gemm([(ge[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=h_prev[:, sl[t]])
             ge = gn
-        dP, dQ, dTe = ops.edge_combine_bwd(ge, pack, R)
-        dEE = _empty(R, F, x)
+        dP, dQ = ops.edge_combine_bwd_pq(ge, pack)
         dx = _empty(N, H, x)
         for t in range(T):
             k0 = pidx(t, "pre", 0)
@@ -456,12 +483,41 @@ class PNAConvFn(torch.autograd.Function):
             xt = x[:, sl[t]]
             ops.queue_wgrad(dP[:, sl[t]], xt, dW0[:, 0:F])
             ops.queue_wgrad(dQ[:, sl[t]], xt, dW0[:, F:2 * F])
-            ops.queue_wgrad(dTe[:, sl[t]], EE, dW0[:, 2 * F:3 * F], dbias=grads[k0 + 1])
-            ops.gemm([(dTe[:, sl[t]], None, W0[:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
             ops.gemm([(g[:, sl[t]], None, params[kp][:, 0:F]), (dP[:, sl[t]], None, W0[:, 0:F]),
                       (dQ[:, sl[t]], None, W0[:, F:2 * F])], dx[:, sl[t]], b_trans=False)
-        ops.queue_wgrad(dEE, BE, d_enc_w, dbias=d_enc_b)
-        dBE = ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False)
+        # Bond-table gradient chain: dTe (by-code segment sum over the 84 MB message gradient) -> the edge slice of
+        # pre-layer 0 -> edge_encoder -> the bond-embedding gradient.  Nothing on the way to dx depends on it, so it runs
+        # on side stream 1 (forked here, i.e. behind the kernel that produced ``ge``) and leaves the critical path.
+        code_pos = ops.bond_code_index(pack, R, H)   # (may build the inverted index: on the main stream, before the fork)
+        acc = ctx.bond_acc
+        dBE_box = []
+        keep = [ge, EE, BE] + ([acc.buf] if acc is not None else [])  # + the chain's temporaries (appended below)
+
+        def bond_chain():
+            dTe = ops.bond_table_grad(ge, pack, R, code_pos)
+            dEE = _empty(R, F, x)
+            for t in range(T):
+                k0 = pidx(t, "pre", 0)
+                ops.gemm_wgrad_inline(dTe[:, sl[t]], EE, grads[k0][:, 2 * F:3 * F], dbias=grads[k0 + 1])
+                ops.gemm([(dTe[:, sl[t]], None, params[k0][:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
+            ops.gemm_wgrad_inline(dEE, BE, d_enc_w, dbias=d_enc_b)
+            if acc is None:
+                dBE_box.append(ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False))
+            else:  # the layers of one model share one accumulator; the layer whose backward runs first clears it
+                if acc.first_in_backward(ctx.layer_index):
+                    ops.zero_(acc.buf)
+                ops.gemm([(dEE, None, enc_w)], acc.buf, b_trans=False, accumulate=True)
+            keep.extend((dTe, dEE))
+
+        if acc is None:
+            bond_chain()  # stand-alone use of the layer: the caller gets dBE back at once, so no side stream
+            dBE = dBE_box[0]
+        else:
+            ops.run_on_second_side_stream(ge, keep, bond_chain)
+            dBE = None
+            if ctx.layer_index == 0:  # the last conv backward of the pass hands the accumulated gradient to autograd
+                ops.join_side_stream(x.device, 1)
+                dBE = acc.buf
         ops.flush_wgrads()  # the layer's weight gradients in batched launches on the weight-gradient stream
         if merged is not None:
             dWm, dbm = merged

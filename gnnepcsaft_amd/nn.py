@@ -198,9 +198,13 @@ class PNAConv(Module):
         return Fn.WeightOnlyAhead(edge_attr, self.towers, self.F_in, self.pre_layers, self.post_layers,
                                   self.aggr_module.avg_log(), self._params(), dc.D if dc is not None else 0)
 
-    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor, prepared=None) -> torch.Tensor:
-        """x fp32[N,H]; edge_index: GraphPack of the batch; edge_attr: fp32[60,H] encoded bond table."""
-        cfg = (self.towers, self.F_in, self.pre_layers, self.post_layers, self.aggr_module.avg_log(), prepared)
+    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor, prepared=None, bond_acc=None,
+                layer_index: int = 0) -> torch.Tensor:
+        """x fp32[N,H]; edge_index: GraphPack of the batch; edge_attr: fp32[60,H] encoded bond table.  ``bond_acc``
+        (optional, ``Fn.BondGradAccumulator`` shared by the ``depth`` layers of a model, this one being number
+        ``layer_index``): the bond-table gradient is accumulated there off the critical path."""
+        cfg = (self.towers, self.F_in, self.pre_layers, self.post_layers, self.aggr_module.avg_log(), prepared,
+               bond_acc, layer_index)
         return Fn.PNAConvFn.apply(x, edge_attr, edge_index, cfg, *self._params())
 
 

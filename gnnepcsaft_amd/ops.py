@@ -380,11 +380,19 @@ def set_wgrad_side_stream(enabled: bool) -> None:
 _JOIN_QUEUED = False
 
 
-def _join(idx: int) -> None:
+_SIDE_USED: dict = {}    # device index -> set of side-stream indices with launches not yet joined
+
+
+def _join(idx: int, which: Optional[int] = None) -> None:
+    """Main stream waits for side stream ``which`` of device ``idx`` (None = every side stream in use)."""
     dev = torch.device("cuda", idx)
-    check(_lib.load().gnx_side_join(handle(dev)))
-    _SIDE_PENDING.discard(idx)
-    _SIDE_KEEP.pop(idx, None)  # later users of these blocks are ordered behind the join on the main stream
+    used = _SIDE_USED.get(idx, set())
+    for w in sorted(used if which is None else (used & {which})):
+        check(_lib.load().gnx_side_join_n(handle(dev), w))
+        used.discard(w)
+    if not used:
+        _SIDE_PENDING.discard(idx)
+        _SIDE_KEEP.pop(idx, None)  # later users of these blocks are ordered behind the join on the main stream
 
 
 def _join_all_side_streams() -> None:
@@ -415,11 +423,16 @@ def set_wgrad_done_hook(fn) -> None:
     _WGRAD_DONE_HOOK = fn
 
 
-def side_stream(device: torch.device) -> "torch.cuda.Stream":
-    """The library's weight-gradient stream as a torch stream object (no ownership)."""
+def side_stream(device: torch.device, which: int = 0) -> "torch.cuda.Stream":
+    """One of the library's side streams (0 = weight gradients, 1 = bond-table chain) as a torch stream (no ownership)."""
     out = C.c_void_p()
-    check(_lib.load().gnx_side_stream(handle(device), C.byref(out)))
+    check(_lib.load().gnx_side_stream_n(handle(device), which, C.byref(out)))
     return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def second_side_stream_in_use(device: torch.device) -> bool:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return 1 in _SIDE_USED.get(idx, set())
 
 
 def wgrad_stream_enabled() -> bool:
@@ -510,14 +523,14 @@ def flush_wgrads() -> None:
             _lib.load().gnx_gemm_wgrad_batched(handle(ref.device), n, arr)))
 
 
-def join_side_stream(device: torch.device) -> None:
-    """Make the current stream wait for all weight-gradient kernels issued on the side stream."""
+def join_side_stream(device: torch.device, which: Optional[int] = None) -> None:
+    """Make the current stream wait for the launches issued on the side stream(s) (``which`` = one of them)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx in _SIDE_PENDING:
-        _join(idx)
+        _join(idx, which)
 
 
-def _run_on_side(ref: torch.Tensor, tensors, fn) -> None:
+def _run_on_side(ref: torch.Tensor, tensors, fn, which: int = 0) -> None:
     """Run ``fn`` (weight-gradient launches) on the library's side stream when enabled, else inline.  ``tensors`` are
     the device buffers the launches read or write; they are kept referenced until the join so the caching allocator
     cannot hand them out again under the side kernels (fork / join are two HIP event calls inside the library:
@@ -525,13 +538,14 @@ def _run_on_side(ref: torch.Tensor, tensors, fn) -> None:
     if _SIDE_ENABLED and ref.is_cuda:
         idx = ref.device.index
         lib, h = _lib.load(), handle(ref.device)
-        check(lib.gnx_side_begin(h))
+        check(lib.gnx_side_begin_n(h, which))
         try:
             fn()
         finally:
             check(lib.gnx_side_end(h))
         _SIDE_KEEP.setdefault(idx, []).extend(t for t in tensors if t is not None)
         _SIDE_PENDING.add(idx)
+        _SIDE_USED.setdefault(idx, set()).add(which)
         return
     fn()
 
@@ -542,9 +556,17 @@ def run_after_wgrads(ref: torch.Tensor, tensors, fn) -> None:
     _run_on_side(ref, tensors, fn)
 
 
-def gemm_wgrad_inline(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor) -> None:
-    """dW += dC^T A on the CURRENT stream of the library handle (inside ``run_after_wgrads`` that is the side stream)."""
-    _gemm_wgrad_launch(dC, A, dW, None, None)
+def run_on_second_side_stream(ref: torch.Tensor, tensors, fn) -> None:
+    """Run ``fn`` on side stream 1 (inline when side streams are off): the bond-table gradient chain of a conv layer's
+    backward -- it forks from the main stream here, feeds parameter gradients and the bond-embedding gradient only, and
+    is joined with the rest at the end of backward (or by ``join_side_stream(device, 1)``)."""
+    _run_on_side(ref, tensors, fn, which=1)
+
+
+def gemm_wgrad_inline(dC: torch.Tensor, A: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None) -> None:
+    """dW += dC^T A (dbias += column sums of dC) on the CURRENT stream of the library handle -- inside
+    ``run_after_wgrads`` / ``run_on_second_side_stream`` that is the side stream."""
+    _gemm_wgrad_launch(dC, A, dW, None, dbias)
 
 
 def axpy_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
@@ -603,27 +625,46 @@ def edge_combine_fwd(P: torch.Tensor, Q: torch.Tensor, Te: torch.Tensor, g: Grap
     return h1
 
 
-def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def edge_combine_bwd_pq(gr: torch.Tensor, g: GraphPack) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dP[i] = sum of g over CSR row i, dQ[j] = sum of g over the edges leaving j (no bond-table gradient)."""
     H = gr.size(1)
     dP = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
     dQ = torch.empty(g.N, H, dtype=torch.float32, device=gr.device)
+    check(_lib.load().gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
+                                           g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, 0, dP.data_ptr(),
+                                           dQ.data_ptr(), None, None, 0))
+    return dP, dQ
+
+
+def bond_table_grad(gr: torch.Tensor, g: GraphPack, R: int, pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """dTe[r] = sum of g over the edges with bond code r; ``pos`` = ``g.code_index(R)`` fetched by the caller (it may
+    build the index, which must not happen on a side stream)."""
+    H = gr.size(1)
     dTe = zeros(R, H, device=gr.device)
     lib = _lib.load()
-    pos = g.code_index(R) if (H % 4 == 0 and H <= 1024) or H <= 256 else None
+    if g.E == 0:
+        return dTe
     if pos is not None:
-        # bond-table gradient through the inverted index (gather-sum, no LDS atomics); dP/dQ from the same call
-        check(lib.gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
-                                       g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(),
-                                       dQ.data_ptr(), None, None, 0))
         check(lib.gnx_key_segment_sum(handle(gr.device), gr.data_ptr(), pos.data_ptr(), g.code.data_ptr(), g.E, H,
                                       dTe.data_ptr()))
-        return dP, dQ, dTe
+        return dTe
+    # more than 64 codes (never the 60-row bond table): the LDS-privatised scatter inside gnx_edge_combine_bwd
     nbytes = lib.gnx_table_scatter_workspace_bytes(g.E, R, H)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=gr.device)
+    tmp = torch.empty(2, g.N, H, dtype=torch.float32, device=gr.device)
     check(lib.gnx_edge_combine_bwd(handle(gr.device), gr.data_ptr(), g.rowptr.data_ptr(), g.colptr.data_ptr(),
-                                   g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, dP.data_ptr(), dQ.data_ptr(),
-                                   dTe.data_ptr(), ws.data_ptr(), nbytes))
-    return dP, dQ, dTe
+                                   g.cpos.data_ptr(), g.code.data_ptr(), g.N, g.E, H, R, tmp[0].data_ptr(),
+                                   tmp[1].data_ptr(), dTe.data_ptr(), ws.data_ptr(), nbytes))
+    return dTe
+
+
+def bond_code_index(g: GraphPack, R: int, H: int) -> Optional[torch.Tensor]:
+    return g.code_index(R) if ((H % 4 == 0 and H <= 1024) or H <= 256) and g.E > 0 else None
+
+
+def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    dP, dQ = edge_combine_bwd_pq(gr, g)
+    return dP, dQ, bond_table_grad(gr, g, R, bond_code_index(g, R, gr.size(1)))
 
 
 def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:

@@ -338,6 +338,12 @@ int32_t gnx_side_begin(gnx_handle* h);
 int32_t gnx_side_stream(gnx_handle* h, void** hip_stream);
 int32_t gnx_side_end(gnx_handle* h);
 int32_t gnx_side_join(gnx_handle* h);
+/* the same with an explicit side-stream index (0 or 1; gnx_side_begin / gnx_side_join are index 0).  Stream 1 carries
+ * the bond-table gradient chain of a conv layer's backward (by-code segment sum -> 60-row products), which feeds only
+ * parameter gradients and the bond-embedding gradient consumed at the very end of backward. */
+int32_t gnx_side_stream_n(gnx_handle* h, int32_t which, void** hip_stream);
+int32_t gnx_side_begin_n(gnx_handle* h, int32_t which);
+int32_t gnx_side_join_n(gnx_handle* h, int32_t which);
 /* y[m,:] = clip(x[m,:], lo[:], hi[:]), NaN propagates like Tensor.clip  (pred_with_bounds, ref: train/models.py:246-253) */
 int32_t gnx_clip_rows(gnx_handle* h, const float* x, int64_t M, int32_t P, const float* lo, const float* hi, float* y);
 
