@@ -93,6 +93,7 @@ SIGNATURES = {
     "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "gnx_gine_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                       _vp, _vp]),
+    "gnx_gine_dle": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_segment_pool_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_segment_pool_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "gnx_batchnorm_workspace_bytes": (_sz, [_i64, _i32]),

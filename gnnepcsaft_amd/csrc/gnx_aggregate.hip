@@ -739,6 +739,24 @@ extern "C" int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, cons
   return GNX_OK;
 }
 
+// dLe alone (the bond-table gradient of GINEConv.lin's output): same kernels as the tail of gnx_gine_aggregate_bwd, as
+// its own entry point so that the caller can run it on a side stream while dx continues on the main one.
+extern "C" int32_t gnx_gine_dle(gnx_handle* h, const float* dout, const float* x, const float* Le, const int32_t* src,
+                                const int32_t* dst, const int32_t* code, const int32_t* code_pos, int64_t E, int32_t H,
+                                int32_t R, float* dLe) {
+  GNX_CHECK_ARG(h && H > 0 && E >= 0 && R > 0, "gnx_gine_dle: bad argument");
+  if (E == 0) return GNX_OK;
+  GNX_CHECK_ARG(dout && x && Le && src && dst && code && dLe, "gnx_gine_dle: NULL argument");
+  gnx_prof_scope prof(h, GNX_K_KEY_SEGMENT_SUM, 8.0 * E * H + 16.0 * E);
+  if (code_pos != nullptr && H % 4 == 0 && H / 4 <= 256) {
+    hipLaunchKernelGGL(k_gine_dle_segment_sum<4>, dim3((unsigned)gnx_cdiv(E, SEG_CHUNK)), dim3(256), 0, h->stream, dout, x,
+                       Le, code_pos, src, dst, code, E, (int)H, dLe);
+    GNX_LAUNCH_CHECK();
+    return GNX_OK;
+  }
+  return gine_dle(h, dout, x, Le, src, dst, code, E, H, R, dLe);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // contiguous segment pool over graph_ptr (global pool): add / mean / max
 // ---------------------------------------------------------------------------------------------------------------

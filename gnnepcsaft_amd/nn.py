@@ -233,10 +233,11 @@ class GINEConv(Module):
             self._eps_cache = c = (self.eps, self.eps._version, float(self.eps.item()))
         return c[2]
 
-    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor, bond_acc=None,
+                layer_index: int = 0) -> torch.Tensor:
         l0, l2 = self.nn[0], self.nn[2]
         return Fn.GINEConvFn.apply(x, edge_attr, edge_index, self.eps_value(), self.lin.weight, self.lin.bias,
-                                   l0.weight, l0.bias, l2.weight, l2.bias)
+                                   l0.weight, l0.bias, l2.weight, l2.bias, bond_acc, layer_index)
 
 
 class BatchNorm1d(torch.nn.BatchNorm1d):

@@ -690,15 +690,25 @@ def gine_aggregate_fwd(x: torch.Tensor, Le: torch.Tensor, g: GraphPack, eps: flo
 
 
 def gine_aggregate_bwd(dout: torch.Tensor, x: torch.Tensor, Le: torch.Tensor, g: GraphPack,
-                       eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+                       eps: float, want_dle: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dx (and, with ``want_dle``, the bond-table gradient dLe from the same call)."""
     dx = torch.empty_like(x)
-    dLe = zeros(*Le.shape, device=Le.device)
-    pos = g.code_index(Le.size(0)) if g.E > 0 else None  # inverted index by bond code (None above 64 codes)
+    dLe = zeros(*Le.shape, device=Le.device) if want_dle else None
+    pos = g.code_index(Le.size(0)) if (g.E > 0 and want_dle) else None  # inverted index by bond code (None above 64 codes)
     check(_lib.load().gnx_gine_aggregate_bwd(handle(x.device), dout.data_ptr(), x.data_ptr(), Le.data_ptr(),
                                              g.colptr.data_ptr(), g.cpos.data_ptr(), g.src.data_ptr(),
                                              g.dst.data_ptr(), g.code.data_ptr(), _ptr(pos), g.N, g.E, x.size(1),
-                                             Le.size(0), float(eps), dx.data_ptr(), dLe.data_ptr()))
+                                             Le.size(0), float(eps), dx.data_ptr(), _ptr(dLe)))
     return dx, dLe
+
+
+def gine_dle(dout: torch.Tensor, x: torch.Tensor, Le: torch.Tensor, g: GraphPack, pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """dLe[r] = sum over the edges with bond code r of dout[dst] * (x[src] + Le[r] > 0), on the handle's current stream."""
+    dLe = zeros(*Le.shape, device=Le.device)
+    check(_lib.load().gnx_gine_dle(handle(x.device), dout.data_ptr(), x.data_ptr(), Le.data_ptr(), g.src.data_ptr(),
+                                   g.dst.data_ptr(), g.code.data_ptr(), _ptr(pos), g.E, x.size(1), Le.size(0),
+                                   dLe.data_ptr()))
+    return dLe
 
 
 _POOL = {"add": _lib.POOL_ADD, "sum": _lib.POOL_ADD, "mean": _lib.POOL_MEAN, "max": _lib.POOL_MAX}

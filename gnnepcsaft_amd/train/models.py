@@ -158,11 +158,10 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
         ahead = None
         if h.is_cuda and ops.wgrad_stream_enabled() and Fn.prepare_ahead_enabled() and hasattr(convs[0], "prepare_ahead"):
             ahead = convs[0].prepare_ahead(pack, bond_table)
-        # PNA: every layer's bond-embedding gradient is accumulated into one buffer on a side stream (its chain feeds no
+        # every layer's bond-embedding gradient is accumulated into one buffer on a side stream (its chain feeds no
         # activation gradient); layer 0, whose backward runs last, returns the total
         acc = None
-        if h.is_cuda and bond_table.requires_grad and torch.is_grad_enabled() and Fn.bond_chain_aside_enabled() and \
-                hasattr(convs[0], "prepare_ahead"):
+        if h.is_cuda and bond_table.requires_grad and torch.is_grad_enabled() and Fn.bond_chain_aside_enabled():
             acc = Fn.BondGradAccumulator(bond_table.size(0), bond_table.size(1), h.device, len(convs))
         for l, (layer, norm) in enumerate(zip(convs, self.batch_norms)):
             extra = {} if acc is None else {"bond_acc": acc, "layer_index": l}

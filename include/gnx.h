@@ -278,6 +278,12 @@ int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, const float* x,
                                const int32_t* code, const int32_t* code_pos, int64_t N, int64_t E, int32_t H, int32_t R,
                                float eps, float* dx, float* dLe);
 
+/* dLe only (what gnx_gine_aggregate_bwd computes when dLe != NULL), as its own call so that it can run on a side
+ * stream beside the dx chain; dLe is ACCUMULATED (+=). */
+int32_t gnx_gine_dle(gnx_handle* h, const float* dout, const float* x, const float* Le, const int32_t* src,
+                     const int32_t* dst, const int32_t* code, const int32_t* code_pos, int64_t E, int32_t H, int32_t R,
+                     float* dLe);
+
 /* ---- contiguous segment reduce: global pool (ref: train/models.py:218-225, 587-595) ------------------------ */
 enum { GNX_POOL_ADD = 0, GNX_POOL_MEAN = 1, GNX_POOL_MAX = 2 };
 int32_t gnx_segment_pool_fwd(gnx_handle* h, const float* x, const int32_t* ptr, int64_t B, int32_t H, int32_t mode,
