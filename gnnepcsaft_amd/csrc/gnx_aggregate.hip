@@ -448,7 +448,7 @@ extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int
 // One workgroup = SEG_CHUNK consecutive entries of pos; a thread owns 4 channels and sums rows in registers, flushing
 // with one atomic per (key run inside the chunk): ~ (#chunks + #keys) x H atomics in total instead of items x H.
 // ---------------------------------------------------------------------------------------------------------------
-#define SEG_CHUNK 64
+#define SEG_CHUNK 128
 
 template <int VEC>
 __global__ void __launch_bounds__(256) k_key_segment_sum(const float* __restrict__ g, const int* __restrict__ pos,
@@ -471,7 +471,8 @@ __global__ void __launch_bounds__(256) k_key_segment_sum(const float* __restrict
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
   int cur = key[pos[a]];
-  constexpr int UN = 8;  // items in flight: index loads batched, then the row gathers batched (a 64-item chunk = one batch per lane)
+  constexpr int UN = 4;  // items in flight: index loads batched, then the row gathers batched (2 round trips per 4).
+  // (64-item chunks with 8 in flight were measured 2x SLOWER: 118 vs 56 us at cfg-2 -- twice the atomic flushes.)
   for (int64_t i = a; i < b; i += UN) {
     int p[UN], k[UN];
     float r[UN][VEC];

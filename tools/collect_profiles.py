@@ -1,8 +1,7 @@
-"""Copies the judged summaries of a profiling run from gpurun_out/ (scratch) into profiles/ (tracked).
+"""Copies the judged summaries of a profiling run (tools/profile_round.sh) from gpurun_out/<tag>/ (scratch) into
+profiles/ (tracked).
 
-usage: python tools/collect_profiles.py <stats_dir> <pmc_dir> <bench_json> [round_tag]
-  stats_dir : rocprofv3 --kernel-trace --stats output (contains */*_kernel_stats.csv and bench.json)
-  pmc_dir   : contains fetch/ and write/ outputs of the two --pmc passes
+usage: python tools/collect_profiles.py [tag]        (default r02; reads gpurun_out/<tag>/)
 """
 import collections
 import csv
@@ -15,34 +14,60 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(stats_dir, pmc_dir, bench_json, tag="r01"):
+def kernel_stats(src_dir, dst):
+    f = glob.glob(os.path.join(src_dir, "*", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f[0], dst)
+        return True
+    return False
+
+
+def main(tag="r02"):
+    src = os.path.join(ROOT, "gpurun_out", tag)
     prof = os.path.join(ROOT, "profiles")
-    shutil.copy(bench_json, os.path.join(prof, f"bench_{tag}.json"))
-    shutil.copy(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0],
-                os.path.join(prof, f"{tag}_kernel_stats_cfg2.csv"))
-    shutil.copy(os.path.join(stats_dir, "bench.json"), os.path.join(prof, f"{tag}_bench_under_rocprof.json"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(prof, f"bench_{tag}.json"))
+    kernel_stats(os.path.join(src, "stats"), os.path.join(prof, f"{tag}_kernel_stats_cfg2.csv"))
+    kernel_stats(os.path.join(src, "stats_ns"), os.path.join(prof, f"{tag}_kernel_stats_cfg2_single_stream.csv"))
+    for c in (3, 5):
+        kernel_stats(os.path.join(src, f"stats_cfg{c}"), os.path.join(prof, f"{tag}_kernel_stats_cfg{c}_single_stream.csv"))
+    for name in ("stats/bench.json", "stats_ns/bench.json"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(prof, f"{tag}_bench_under_rocprof{'_single_stream' if 'ns' in name else ''}.json"))
+    for c in (1, 3, 4, 5):
+        f = os.path.join(src, f"bench_cfg{c}.json")
+        if os.path.exists(f) and os.path.getsize(f) > 0:
+            shutil.copy(f, os.path.join(prof, f"{tag}_bench_cfg{c}.json"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for which in ("fetch", "write"):
-        f = glob.glob(os.path.join(pmc_dir, which, "*", "*_counter_collection.csv"))[0]
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    with open(os.path.join(prof, f"{tag}_pmc_fetch_write_per_kernel.csv"), "w", newline="") as fh:
-        w = csv.writer(fh)
-        w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_avg(2*FETCH+WRITE)"])
-        for k in sorted(agg, key=lambda k: -sum(agg[k].get("FETCH_SIZE", [0]))):
-            fs, ws = agg[k].get("FETCH_SIZE", []), agg[k].get("WRITE_SIZE", [])
-            fa = sum(fs) / max(len(fs), 1)
-            wa = sum(ws) / max(len(ws), 1)
-            w.writerow([k[:90], max(len(fs), len(ws)), f"{fa:.1f}", f"{wa:.1f}", f"{(2 * fa + wa) * 1024:.0f}"])
-    key = [k for k in agg if k.startswith("void k_pna_agg_fwd")]
-    if key:
-        fs, ws = agg[key[0]]["FETCH_SIZE"], agg[key[0]]["WRITE_SIZE"]
-        fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
-        old = json.load(open(os.path.join(prof, "pmc_scatter.json")))
-        old.update({"FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
-                    "workload": f"bench.py cfg-2 (N=81920, E=163840, H=128), {len(fs)} dispatches per counter pass"})
-        json.dump(old, open(os.path.join(prof, "pmc_scatter.json"), "w"), indent=1)
-        print("scatter traffic/launch", (2 * fa + wa) * 1024, "algorithmic", old["algorithmic_bytes_per_launch"])
+        fs = glob.glob(os.path.join(src, "pmc", which, "*", "*_counter_collection.csv"))
+        if not fs:
+            continue
+        for r in csv.DictReader(open(fs[0])):
+            # bench.py also times the scatter kernel on a 16 384-graph batch (roofline.large): keep the cfg-2 launches
+            # (81 920 atoms x 32 threads) apart from those
+            name = r["Kernel_Name"]
+            if name.startswith("void k_pna_agg_fwd") and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) != 81920 * 32:
+                name += " [16384-graph batch]"
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if agg:
+        with open(os.path.join(prof, f"{tag}_pmc_fetch_write_per_kernel.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_avg(2*FETCH+WRITE)"])
+            for k in sorted(agg, key=lambda k: -sum(agg[k].get("FETCH_SIZE", [0]))):
+                fs_, ws_ = agg[k].get("FETCH_SIZE", []), agg[k].get("WRITE_SIZE", [])
+                fa = sum(fs_) / max(len(fs_), 1)
+                wa = sum(ws_) / max(len(ws_), 1)
+                w.writerow([k[:90], max(len(fs_), len(ws_)), f"{fa:.1f}", f"{wa:.1f}", f"{(2 * fa + wa) * 1024:.0f}"])
+        key = [k for k in agg if k.startswith("void k_pna_agg_fwd") and not k.endswith("batch]")]
+        if key:
+            fs_, ws_ = agg[key[0]]["FETCH_SIZE"], agg[key[0]]["WRITE_SIZE"]
+            fa, wa = sum(fs_) / len(fs_), sum(ws_) / len(ws_)
+            old = json.load(open(os.path.join(prof, "pmc_scatter.json")))
+            old.update({"FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
+                        "conv": "PNA", "N": 81920, "E": 163840, "H": 128, "round": tag,
+                        "workload": f"bench.py cfg-2 (N=81920, E=163840, H=128), {len(fs_)} dispatches per counter pass"})
+            json.dump(old, open(os.path.join(prof, "pmc_scatter.json"), "w"), indent=1)
+            print("scatter traffic/launch", (2 * fa + wa) * 1024, "algorithmic", old["algorithmic_bytes_per_launch"])
 
 
 if __name__ == "__main__":
