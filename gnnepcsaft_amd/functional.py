@@ -270,9 +270,27 @@ class BondGradAccumulator:
     def __init__(self, R: int, H: int, device, depth: int):
         self.buf = torch.empty(R, H, dtype=torch.float32, device=device)
         self.depth = depth
+        self.encoder = None  # (combos, offsets, tables) of the BondEncoder whose table() this gradient belongs to
 
     def first_in_backward(self, layer_index: int) -> bool:
         return layer_index == self.depth - 1
+
+    def handoff(self, device) -> Optional[torch.Tensor]:
+        """Called by the conv layer whose backward runs last.  If the bond encoder's tables have in-place gradient
+        sinks (``set_grad_in_place`` + a flat gradient buffer), the encoder's own backward -- a scatter of the 60
+        accumulated rows into the three tables -- is issued right here on side stream 1, behind the chain, and autograd
+        gets ``None`` for the bond table: the main stream never waits for the chain.  Otherwise the main stream joins
+        side stream 1 and the accumulated gradient goes back to autograd as usual."""
+        if self.encoder is not None:
+            idx, offs, weights = self.encoder
+            sinks = grad_sinks(weights)
+            gtable = adjacent_rows(sinks) if all(g is not None for g in sinks) else None
+            if gtable is not None:
+                buf = self.buf
+                ops.run_on_second_side_stream(buf, [buf, idx, gtable], lambda: ops.embed_sum_bwd(idx, offs, buf, out=gtable))
+                return None
+        ops.join_side_stream(device, 1)
+        return self.buf
 
 
 class WeightOnlyAhead:
@@ -516,8 +534,7 @@ class PNAConvFn(torch.autograd.Function):
             ops.run_on_second_side_stream(ge, keep, bond_chain)
             dBE = None
             if ctx.layer_index == 0:  # the last conv backward of the pass hands the accumulated gradient to autograd
-                ops.join_side_stream(x.device, 1)
-                dBE = acc.buf
+                dBE = acc.handoff(x.device)
         ops.flush_wgrads()  # the layer's weight gradients in batched launches on the weight-gradient stream
         if merged is not None:
             dWm, dbm = merged
@@ -591,8 +608,7 @@ class GINEConvFn(torch.autograd.Function):
             ops.run_on_second_side_stream(dagg, keep, bond_chain)
             dBE = None
             if ctx.layer_index == 0:
-                ops.join_side_stream(x.device, 1)
-                dBE = acc.buf
+                dBE = acc.handoff(x.device)
         ops.finish_backward(x.device, all(k is not None for k in sk), sk)
         outs = [None if k is not None else g_ for g_, k in zip((dlw, dlb, dw0, db0, dw2, db2), sk)]
         return (dx, dBE, None, None, *outs, None, None)

@@ -297,8 +297,9 @@ def gemm(segs: Sequence[Seg], out: torch.Tensor, *, bias: Optional[torch.Tensor]
             (_lib.GEMM_B_TRANS if b_trans else 0)
     mp, ldm = (None, 0) if mask is None else _mat(mask, "mask")
     lib, h = _lib.load(), handle(out.device)
-    # split weight images of the tiled split-operand kernel live in caller-owned scratch (0 bytes for most calls)
-    nbytes = lib.gnx_gemm_workspace_bytes(h, len(segs), arr, None, 1, M, N, mp, flags, 0)
+    # split weight images of the tiled split-operand kernel live in caller-owned scratch (0 bytes for most calls; the
+    # split path needs >= 4096 rows, so small products skip the query: host time matters in tiny-kernel phases)
+    nbytes = lib.gnx_gemm_workspace_bytes(h, len(segs), arr, None, 1, M, N, mp, flags, 0) if M >= 4096 else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device) if nbytes else None
     check(lib.gnx_gemm(h, len(segs), arr, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags, _ptr(ws), nbytes))
     return out

@@ -163,6 +163,7 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
         acc = None
         if h.is_cuda and bond_table.requires_grad and torch.is_grad_enabled() and Fn.bond_chain_aside_enabled():
             acc = Fn.BondGradAccumulator(bond_table.size(0), bond_table.size(1), h.device, len(convs))
+            acc.encoder = (self.edge_embed.combos, self.edge_embed.offsets, self.edge_embed._weights())
         for l, (layer, norm) in enumerate(zip(convs, self.batch_norms)):
             extra = {} if acc is None else {"bond_acc": acc, "layer_index": l}
             if ahead is not None:
