@@ -22,7 +22,8 @@ def _lone():
 
 
 # name: (cfg overrides, recipe).  recipe: graphs, gen (synthetic generator config index), optional seed /
-# molecule_like / special ("lone": single-atom graphs interleaved, "hubs": star graphs with > 64 in-degrees)
+# molecule_like / special ("lone": single-atom graphs interleaved, "hubs": star graphs with > 64 in-degrees,
+# "esper": real molecules from tests/golden/esper_smiles_sample.tsv through gnnepcsaft_amd.data.featurize)
 MODEL_CASES: Dict[str, Tuple[dict, dict]] = {
     # --- the 32-graph shape sweep
     "pna_small": (dict(hidden_dim=64, propagation_depth=2), dict(graphs=32, gen=1)),
@@ -53,6 +54,10 @@ MODEL_CASES: Dict[str, Tuple[dict, dict]] = {
     "pna_lone_atoms": (dict(hidden_dim=32, propagation_depth=2), dict(special="lone")),
     "gine_lone_atoms": (dict(conv="GINE", hidden_dim=32, propagation_depth=2), dict(special="lone")),
     "pna_hubs": (dict(hidden_dim=64, propagation_depth=2), dict(special="hubs")),
+    # --- real molecules: 94 rows of the reference's Esper table through the SMILES featuriser (1..40 heavy atoms,
+    #     aromatic rings, single-atom molecules, labels = the table's m / sigma / epsilon)
+    "pna_esper_molecules": (dict(hidden_dim=64, propagation_depth=3), dict(special="esper")),
+    "gine_esper_molecules": (dict(conv="GINE", hidden_dim=64, propagation_depth=3), dict(special="esper")),
     # --- batches that select the large-batch kernels (>= 4096 / 8192 rows)
     "pna_cfg2_shape_256": (dict(hidden_dim=128, propagation_depth=6), dict(graphs=256, gen=2)),
     "pna_large_l2": (dict(hidden_dim=128, propagation_depth=2), dict(graphs=640, gen=2)),
@@ -74,6 +79,14 @@ def build_case(name: str):
         base = synthetic_batch(6, 2).to_data_list()
         lone = _lone()
         batch = Batch.from_data_list([lone, base[0], lone, base[1], base[2], lone])
+    elif special == "esper":
+        import os
+        import torch
+        from gnnepcsaft_amd.data.featurize import from_smiles
+        rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                       "esper_smiles_sample.tsv")) if not ln.startswith("#")]
+        batch = Batch.from_data_list([from_smiles(s, para=torch.tensor([[float(m), float(sg), float(ep)]]),
+                                                  assoc=torch.tensor([[1.0, 3.0]])) for s, m, sg, ep in rows])
     elif special == "hubs":
         from tests.conv_cases import hub_batch
         batch = hub_batch(graphs=24)
