@@ -1,6 +1,10 @@
 """Inference engine: BatchNorm folded into the preceding Linear, weight-only tables precomputed.
 Against the CPU oracle in eval mode and against the unfolded native model, PNA (with towers) and GINE, batched and
-``batch=None`` single-molecule form, ``pred_with_bounds`` clipping, hub-heavy fallback."""
+``batch=None`` single-molecule form, ``pred_with_bounds`` clipping, hub-heavy fallback.
+
+Tolerance against the oracle: the fp64 oracle is the arbiter and the bound is max(1e-5, 1.5 x the reference's own fp32
+reproducibility on the same inputs) -- the eval-mode forward still contains StdAggregation's hard mask, so the CPU fp32
+oracle on permuted-equivalent presentations of the batch is evaluated alongside (tests/parity_util.py explains)."""
 import copy
 
 import pytest
@@ -9,6 +13,19 @@ import torch
 from tests.parity_util import make_models, rel_err
 
 pytestmark = pytest.mark.gpu
+
+
+def _bound_vs_fp64(oracle, batch, draws: int = 6):
+    """(fp64 prediction, max(1e-5, 1.5 x max over fp32 draws of the oracle's distance to it))."""
+    from tests.model_cases import permuted_copy
+    o64 = copy.deepcopy(oracle).double().eval()
+    with torch.no_grad():
+        ref64 = o64(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+        worst = rel_err(oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch), ref64)
+        for d in range(1, draws):
+            pb, gp, _ = permuted_copy(batch, 77 + d)
+            worst = max(worst, rel_err(oracle(pb.x, pb.edge_index, pb.edge_attr, pb.batch), ref64[gp]))
+    return ref64, max(1e-5, 1.5 * worst)
 
 
 def _trained_like(cfg, batch):
@@ -48,14 +65,19 @@ def test_engine_matches_eval_model_and_oracle(gpu_device, kw):
     out = eng(bd.x, bd.edge_index, bd.edge_attr, bd.batch)
     assert out.shape == ref.shape
     assert rel_err(out, nat) <= 1e-5, "folded engine vs unfolded native eval model"
-    assert rel_err(out, ref) <= 2e-5, "folded engine vs CPU oracle in eval mode"
+    ref64, bound = _bound_vs_fp64(oracle, batch)
+    assert rel_err(out, ref64) <= bound, ("folded engine vs fp64 oracle in eval mode", rel_err(out, ref64), bound)
+    assert rel_err(nat, ref64) <= bound, ("native eval model vs fp64 oracle", rel_err(nat, ref64), bound)
     # single molecule, batch=None (demo/utils.py:950), and the clipped form
     one = batch.to_data_list()[5].to("cuda:0")
     with torch.no_grad():
         ref1 = oracle(one.x.cpu(), one.edge_index.cpu(), one.edge_attr.cpu(), None)
         refb = oracle.pred_with_bounds(batch)
-    assert rel_err(eng(one.x, one.edge_index, one.edge_attr, None), ref1) <= 2e-5
-    assert rel_err(eng.pred_with_bounds(bd), refb) <= 2e-5
+    with torch.no_grad():
+        o64 = copy.deepcopy(oracle).double()
+        ref1_64 = o64(one.x.cpu(), one.edge_index.cpu(), one.edge_attr.cpu(), None)
+    assert rel_err(eng(one.x, one.edge_index, one.edge_attr, None), ref1_64) <= max(1e-5, 1.5 * rel_err(ref1, ref1_64))
+    assert rel_err(eng.pred_with_bounds(bd), refb) <= bound
     with pytest.raises(ValueError):
         bad = copy.copy(bd)
         bad.x = None
@@ -75,7 +97,9 @@ def test_engine_large_batch_and_hub_fallback(gpu_device):
     bd = batch.to("cuda:0")
     with torch.no_grad():
         ref = oracle(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
-    assert rel_err(eng(bd.x, bd.edge_index, bd.edge_attr, bd.batch), ref) <= 1e-4
+    ref64, bound = _bound_vs_fp64(oracle, batch, draws=4)
+    got = eng(bd.x, bd.edge_index, bd.edge_attr, bd.batch)
+    assert rel_err(got, ref64) <= bound, (rel_err(got, ref64), bound)
     # a star graph with 100 leaves: in-degree 100 on the hub -> no degree classes
     n = 101
     src = torch.arange(1, n)
@@ -87,7 +111,10 @@ def test_engine_large_batch_and_hub_fallback(gpu_device):
     with torch.no_grad():
         ref_m = oracle(mixed.x, mixed.edge_index, mixed.edge_attr, mixed.batch)
     md = mixed.to("cuda:0")
-    assert rel_err(eng(md.x, md.edge_index, md.edge_attr, md.batch), ref_m) <= 1e-4
+    mixed.ptr = torch.tensor([0, n] + [n + 20 * (k + 1) for k in range(3)])
+    ref64_m, bound_m = _bound_vs_fp64(oracle, mixed, draws=4)
+    got_m = eng(md.x, md.edge_index, md.edge_attr, md.batch)
+    assert rel_err(got_m, ref64_m) <= bound_m, (rel_err(got_m, ref64_m), bound_m)
 
 
 def test_single_molecule_graph_replay(gpu_device):
