@@ -190,3 +190,49 @@ def test_split_weight_gradient_by_degree_class(gpu_device):
     ops.join_side_stream(gpu_device)
     assert rel_err(dW[:, F:], ref[:, F:]) <= TOL
     assert float(dW[:, :F].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("K,nseg", [(640, 2), (1664, 4), (128, 1)])
+@pytest.mark.parametrize("kind", ["cancelling", "denormal_range", "mixed_magnitude"])
+def test_split_product_is_fp32_faithful_at_layer_widths(gpu_device, K, nseg, kind):
+    """the three-bf16-piece product beyond K = 128 -- post-layer 0's K = 640 (5F) and the reference
+    formulation's K = 1664 (13F), as multi-segment products -- on the inputs that stress it:
+      * cancelling: rows whose terms alternate in sign and nearly cancel (|sum| << sum |a||b|), where dropping
+        correction terms or absorbing them in the leading accumulator would show;
+      * denormal_range: operands around 1e-30 .. 1e-38 (third bf16 pieces and some products underflow);
+      * mixed_magnitude: full 24-bit significands spread over 12 orders of magnitude.
+    Error against fp64, normalised by sum_k |a||b| (what fp32 rounding scales with), must stay at the level of the
+    exact-fp32 MFMA kernel; for the denormal case the normaliser is floored at the smallest normal fp32."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(100 + K)
+    M, N = 8192, 128
+    a = torch.randn(M, K)
+    w = torch.randn(N, K) / 8
+    if kind == "cancelling":
+        base = torch.randn(M, K // 2)
+        a = torch.stack([base, -base * (1 + 1e-4 * torch.randn(M, K // 2))], dim=2).reshape(M, K)
+        w = torch.repeat_interleave(torch.randn(N, K // 2), 2, dim=1) * (1 + 1e-6 * torch.randn(N, K))
+    elif kind == "denormal_range":
+        a = a * 1e-19 * torch.exp(2 * torch.randn(M, K))
+        w = w * 1e-15
+    else:
+        a = a * torch.exp(4 * torch.randn(M, K))
+    ad, wd = a.to(gpu_device), w.to(gpu_device)
+    ref = a.double() @ w.double().T
+    norm = (a.double().abs() @ w.double().abs().T).clamp_min(1.1754943508222875e-38)
+    step = K // nseg
+    segs = [(ad[:, i * step:(i + 1) * step], None, wd[:, i * step:(i + 1) * step]) for i in range(nseg)]
+    errs = {}
+    for mode in (1, 0):
+        ops.set_option(gpu_device, _lib.OPT_GEMM_SPLIT, mode)
+        try:
+            out = torch.empty(M, N, device=gpu_device)
+            ops.gemm(segs, out)
+            errs[mode] = float(((out.double().cpu() - ref).abs() / norm).max())
+        finally:
+            ops.set_option(gpu_device, _lib.OPT_GEMM_SPLIT, 1)
+    eps32 = 2.0 ** -24
+    print(K, kind, {k: v / eps32 for k, v in errs.items()})
+    # the exact-fp32 MFMA chain: error grows ~ sqrt(K) roundings; the split product sums 16 exact products per rounding
+    assert errs[0] <= (8 + 2 * K ** 0.5) * eps32
+    assert errs[1] <= max(8 * eps32, 1.25 * errs[0])
