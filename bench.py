@@ -155,9 +155,12 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10, help="(kept for compatibility; the baseline protocol is fixed)")
     ap.add_argument("--no-side-stream", action="store_true", help="keep weight-gradient kernels on the main stream")
     ap.add_argument("--no-degree-classes", action="store_true", help="PNA post-layer 0 as the 13F-wide 4-segment product")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the step into a HIP graph and replay it (measured: no gain over eager launches here — "
-                         "dependent-kernel boundaries cost the same either way and the CPU already runs ahead)")
+    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+                    help="eager: ~360 kernel launches per step from Python; graph: the step captured once into a HIP graph "
+                         "and replayed (immune to a slow or contended host CPU, ~7 %% slower than eager when the host "
+                         "keeps up: replay serialises the streams); auto (default): both are timed on a few untimed "
+                         "probe steps after the warm-up and the faster one runs the timed region")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse launch + barrier + exchange on the CPU (gloo); no kernels, value 0")
     ap.add_argument("--force-dp", action="store_true",
@@ -165,6 +168,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one all-reduce after backward instead of per-layer slices started during backward")
     args = ap.parse_args()
+    if args.graph:
+        args.launch = "graph"
 
     if args.gpus < 1:
         print("[bench] --gpus must be >= 1", file=sys.stderr)
@@ -239,7 +244,7 @@ def main():
     # gradient exchange: every conv layer's slice of the flat buffer is handed to RCCL as soon as that layer's
     # weight-gradient launches are issued (overlaps the rest of backward); the remainder follows after backward;
     # finish() waits stream-wise and turns the sum into the average with one gnx_scale launch
-    flat.enable_overlap(not args.no_overlap and not args.graph)
+    flat.enable_overlap(not args.no_overlap and args.launch != "graph")
 
     def eager_step():
         loss = step_body()
@@ -252,12 +257,19 @@ def main():
     ops.check_range(dev)  # validates the integer inputs of the warm-up steps (sync)
     torch.cuda.synchronize()
 
-    # Optional: the whole step (pack + forward + loss + backward, both streams) captured once into a HIP graph and
-    # replayed; the batch lives in static device buffers.  The gradient all-reduce stays outside the graph.
+    # Launch mode.  Eager = every kernel launched from Python (the host must stay ahead of the GPU: ~6 ms of host time
+    # per step against ~8 ms of GPU time at cfg-2); graph = the whole step (pack + forward + loss + backward, all
+    # streams) captured once into a HIP graph and replayed, the batch living in static device buffers and the gradient
+    # exchange staying outside.  On a fast host eager wins by ~7 % (replay serialises the streams); on a slow or
+    # contended host the graph wins.  "auto" measures both on untimed probe steps and keeps the faster one -- every
+    # rank takes the same decision (max over ranks), because the exchange pattern differs between the modes.
     step = eager_step
     graphed = False
-    if args.graph:
+    autotune = None
+    if args.launch in ("graph", "auto"):
+        overlap_was = flat._overlap
         try:
+            flat.enable_overlap(False)  # collectives cannot be captured: one exchange after the replay instead
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=main_stream):
                 static_loss = step_body()
@@ -270,10 +282,34 @@ def main():
             for _ in range(2):
                 graph_step()
             torch.cuda.synchronize()
-            step, graphed = graph_step, True
+            use_graph = True
+            if args.launch == "auto":
+                def probe(fn, n=8):
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t_) / n * 1e3
+
+                t_graph = probe(graph_step)
+                flat.enable_overlap(overlap_was)
+                t_eager = probe(eager_step)
+                if dist is not None:
+                    tt = torch.tensor([t_eager, t_graph], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t_eager, t_graph = float(tt[0]), float(tt[1])
+                use_graph = t_graph < t_eager
+                autotune = {"probe_steps": 8, "eager_ms": t_eager, "graph_ms": t_graph}
+            if use_graph:
+                flat.enable_overlap(False)
+                step, graphed = graph_step, True
+            else:
+                flat.enable_overlap(overlap_was)
         except Exception as e:  # pylint: disable=broad-except
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
+            flat.enable_overlap(overlap_was)
             step = eager_step
 
     agg_k = _lib.K_PNA_AGG_FWD if cfg["conv"] == "PNA" else _lib.K_GINE_AGG_FWD
@@ -378,6 +414,7 @@ def main():
                                    f"towers={T} pre={cfg['pre_layers']} post={cfg['post_layers']}, {per_gpu} graphs/GPU "
                                    f"({N_nodes} atoms, {E_edges} directed bonds), fwd+loss+bwd incl. CSR packing",
                        "graphs_per_gpu": per_gpu, "parallelism": f"dp{world}", "hip_graph": graphed,
+                       "launch": args.launch, "launch_autotune": autotune,
                        "grad_allreduce_bytes": flat.nbytes if flat.collective else 0,
                        "grad_exchange": ("rccl, %d per-layer slices overlapped with backward + 1" % len(flat.layer_slices)
                                          if flat._overlap else ("rccl, one call after backward" if flat.collective

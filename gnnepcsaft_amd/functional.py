@@ -78,6 +78,16 @@ def grad_sinks(params: Sequence[torch.Tensor]) -> tuple:
     return tuple(out)
 
 
+def _tower_slices(T: int, F: int):
+    """Column slice of every tower; ``None`` for the single-tower layout (the whole tensor, no view is created: a view
+    costs ~2 us of host time and the backward of one layer would create ~40 of them)."""
+    return [None] if T == 1 else [slice(t * F, (t + 1) * F) for t in range(T)]
+
+
+def _cols(t: torch.Tensor, sl_t):
+    return t if sl_t is None else t[:, sl_t]
+
+
 def _empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
 
@@ -244,13 +254,13 @@ def _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
     R, H = BE.size(0), T * F
     enc_w, enc_b, lin_w, lin_b = params[:4]
     per = 2 * (pre_layers + post_layers)
-    sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+    sl = _tower_slices(T, F)
     EE = ops.gemm([(BE, None, enc_w)], _empty(R, F, BE), bias=enc_b)
     Te = _empty(R, H, BE)
     weffs, last = [], []
     for t in range(T):
         W0, b0 = params[4 + t * per], params[4 + t * per + 1]
-        ops.gemm([(EE, None, W0[:, 2 * F:3 * F])], Te[:, sl[t]], bias=b0)
+        ops.gemm([(EE, None, W0[:, 2 * F:3 * F])], _cols(Te, sl[t]), bias=b0)
         Wp = params[4 + t * per + 2 * pre_layers]
         if D > 0:
             weffs.append(ops.pna_weff(Wp, F, D, avg_deg_log))
@@ -300,11 +310,11 @@ class WeightOnlyAhead:
 
     def __init__(self, BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
         self.device = BE.device
-        with torch.no_grad():
-            box = []
-            args = (BE.detach(), T, F, pre_layers, post_layers, avg_deg_log, [p.detach() for p in params], D)
-            ops.run_after_wgrads(BE, (), lambda: box.append(_pna_weight_only(*args)))
-            self.value = box[0]
+        box = []
+        # raw kernel launches on .data pointers: nothing here is recorded by autograd, so no detach() is needed
+        ops.run_after_wgrads(BE, (), lambda: box.append(_pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log,
+                                                                        params, D)))
+        self.value = box[0]
 
     def wait(self):
         ops.join_side_stream(self.device)
@@ -316,9 +326,9 @@ def _merge_last_post_with_lin(lin_w, lin_b, last, sl, like):
     H = lin_w.size(0)
     Wm, bm = _empty(H, H, like), _empty(1, H, like)
     for t, (Wt, _) in enumerate(last):
-        ops.gemm([(lin_w[:, sl[t]], None, Wt)], Wm[:, sl[t]], b_trans=False)       # [H,F] @ [F,F]
+        ops.gemm([(_cols(lin_w, sl[t]), None, Wt)], _cols(Wm, sl[t]), b_trans=False)       # [H,F] @ [F,F]
     for t, (_, bt) in enumerate(last):  # bm = lin_b + sum_t b_t @ lin_w[:, t]^T   (no torch.cat: may run on the side stream)
-        ops.gemm([(bt.view(1, -1), None, lin_w[:, sl[t]])], bm, bias=lin_b if t == 0 else None, accumulate=t > 0)
+        ops.gemm([(bt.view(1, -1), None, _cols(lin_w, sl[t]))], bm, bias=lin_b if t == 0 else None, accumulate=t > 0)
     return Wm, bm.view(-1)
 
 
@@ -330,10 +340,10 @@ def _unmerge_last_post_and_lin(dWm, dbm, lin_w, d_lin_w, d_lin_b, last, last_bia
     row, col = dbm.view(1, -1), dbm.view(-1, 1)
     for t, (Wt, dWt, dbt) in enumerate(last):
         bt = last_bias[t]
-        ops.gemm([(dWm[:, sl[t]], None, Wt)], d_lin_w[:, sl[t]], accumulate=True)                   # [H,F] @ [F,F]^T
-        ops.gemm([(col, None, bt.view(-1, 1))], d_lin_w[:, sl[t]], accumulate=True)                  # [H,1] @ [F,1]^T
-        ops.gemm_wgrad_inline(lin_w[:, sl[t]], dWm[:, sl[t]], dWt)                                   # [H,F]^T [H,F]
-        ops.gemm([(row, None, lin_w[:, sl[t]])], dbt.view(1, -1), b_trans=False, accumulate=True)    # [1,H] @ [H,F]
+        ops.gemm([(_cols(dWm, sl[t]), None, Wt)], _cols(d_lin_w, sl[t]), accumulate=True)                   # [H,F] @ [F,F]^T
+        ops.gemm([(col, None, bt.view(-1, 1))], _cols(d_lin_w, sl[t]), accumulate=True)                  # [H,1] @ [F,1]^T
+        ops.gemm_wgrad_inline(_cols(lin_w, sl[t]), _cols(dWm, sl[t]), dWt)                                   # [H,F]^T [H,F]
+        ops.gemm([(row, None, _cols(lin_w, sl[t]))], dbt.view(1, -1), b_trans=False, accumulate=True)    # [1,H] @ [H,F]
     ops.axpy_(d_lin_b, dbm)
 
 
@@ -361,7 +371,7 @@ class PNAConvFn(torch.autograd.Function):
                for t in range(T)]
         post = [[(params[4 + t * per + 2 * (pre_layers + i)], params[4 + t * per + 2 * (pre_layers + i) + 1])
                  for i in range(post_layers)] for t in range(T)]
-        sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+        sl = _tower_slices(T, F)
         # degree classes: amp/att depend on the in-degree only, so with rows grouped by degree class the 12F-wide scaled
         # operand of post-layer 0 collapses to A @ Weff(d)^T; hub-heavy batches (> 64 classes) keep 4 segments
         dc = pack.degree_classes(pack.max_degree_hint) if _USE_DEGREE_CLASSES else None
@@ -373,16 +383,16 @@ class PNAConvFn(torch.autograd.Function):
         P, Q = _empty(N, H, x), _empty(N, H, x)
         for t in range(T):
             W0 = pre[t][0][0]
-            xt = x[:, sl[t]]
-            ops.gemm([(xt, None, W0[:, 0:F])], P[:, sl[t]])
-            ops.gemm([(xt, None, W0[:, F:2 * F])], Q[:, sl[t]])
+            xt = _cols(x, sl[t])
+            ops.gemm([(xt, None, W0[:, 0:F])], _cols(P, sl[t]))
+            ops.gemm([(xt, None, W0[:, F:2 * F])], _cols(Q, sl[t]))
         h = ops.edge_combine_fwd(P, Q, Te, pack, relu=pre_layers > 1)
         hs = [h]
         for i in range(1, pre_layers):
             hn = _empty(E, H, x)
             for t in range(T):
                 Wi, bi = pre[t][i]
-                ops.gemm([(h[:, sl[t]], None, Wi)], hn[:, sl[t]], bias=bi, relu=i < pre_layers - 1)
+                ops.gemm([(_cols(h, sl[t]), None, Wi)], _cols(hn, sl[t]), bias=bi, relu=i < pre_layers - 1)
             h = hn
             hs.append(h)
         A = ops.pna_aggregate_fwd(h, pack, T, F)
@@ -392,18 +402,18 @@ class PNAConvFn(torch.autograd.Function):
             Wp, bp = post[t][0]
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
             if dc is not None:
-                ops.gemm_grouped([(x[:, sl[t]], None, Wp[:, 0:F], 0), (At, None, weffs[t][0], 4 * F * F)], z[:, sl[t]], dc,
+                ops.gemm_grouped([(_cols(x, sl[t]), None, Wp[:, 0:F], 0), (At, None, weffs[t][0], 4 * F * F)], _cols(z, sl[t]), dc,
                                  bias=bp, relu=post_layers > 1)
             else:
-                ops.gemm([(x[:, sl[t]], None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
-                          (At, att, Wp[:, 9 * F:13 * F])], z[:, sl[t]], bias=bp, relu=post_layers > 1)
+                ops.gemm([(_cols(x, sl[t]), None, Wp[:, 0:F]), (At, None, Wp[:, F:5 * F]), (At, amp, Wp[:, 5 * F:9 * F]),
+                          (At, att, Wp[:, 9 * F:13 * F])], _cols(z, sl[t]), bias=bp, relu=post_layers > 1)
         zs = [z]
         merged = Wm is not None
         for i in range(1, post_layers - 1 if merged else post_layers):
             zn = _empty(N, H, x)
             for t in range(T):
                 Wi, bi = post[t][i]
-                ops.gemm([(z[:, sl[t]], None, Wi)], zn[:, sl[t]], bias=bi, relu=i < post_layers - 1)
+                ops.gemm([(_cols(z, sl[t]), None, Wi)], _cols(zn, sl[t]), bias=bi, relu=i < post_layers - 1)
             z = zn
             zs.append(z)
         if merged:
@@ -440,7 +450,7 @@ class PNAConvFn(torch.autograd.Function):
         def pidx(t, kind, i):  # index of (w) in params/grads
             return 4 + t * per + 2 * (i if kind == "pre" else pre_layers + i)
 
-        sl = [slice(t * F, (t + 1) * F) for t in range(T)]
+        sl = _tower_slices(T, F)
         dout = dout.contiguous()
         merged = None
         if ctx.Wm is not None:
@@ -462,17 +472,17 @@ class PNAConvFn(torch.autograd.Function):
             gn = _empty(N, H, x)
             for t in range(T):
                 k = pidx(t, "post", i)
-                ops.queue_wgrad(g[:, sl[t]], a_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
-                ops.gemm([(g[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=a_prev[:, sl[t]])
+                ops.queue_wgrad(_cols(g, sl[t]), _cols(a_prev, sl[t]), grads[k], dbias=grads[k + 1])
+                ops.gemm([(_cols(g, sl[t]), None, params[k])], _cols(gn, sl[t]), b_trans=False, mask=_cols(a_prev, sl[t]))
             g = gn
         # post layer 0: 4-segment weight gradient, 3-segment dA
         dA = _empty(N, T * 4 * F, x)
         for t in range(T):
             k = pidx(t, "post", 0)
             Wp, dWp = params[k], grads[k]
-            gt = g[:, sl[t]]
+            gt = _cols(g, sl[t])
             At = A[:, t * 4 * F:(t + 1) * 4 * F]
-            ops.queue_wgrad(gt, x[:, sl[t]], dWp[:, 0:F], dbias=grads[k + 1])
+            ops.queue_wgrad(gt, _cols(x, sl[t]), dWp[:, 0:F], dbias=grads[k + 1])
             if ctx.dc is not None:
                 ops.pna_post0_wgrad_classes(gt, At, ctx.dc, F, ctx.cfg[4], dWp)
                 ops.gemm_grouped([(gt, None, ctx.weffs[t][0], 4 * F * F)], dA[:, t * 4 * F:(t + 1) * 4 * F], ctx.dc,
@@ -489,8 +499,8 @@ class PNAConvFn(torch.autograd.Function):
             gn = _empty(E, H, x)
             for t in range(T):
                 k = pidx(t, "pre", i)
-                ops.queue_wgrad(ge[:, sl[t]], h_prev[:, sl[t]], grads[k], dbias=grads[k + 1])
-                ops.gemm([(ge[:, sl[t]], None, params[k])], gn[:, sl[t]], b_trans=False, mask=h_prev[:, sl[t]])
+                ops.queue_wgrad(_cols(ge, sl[t]), _cols(h_prev, sl[t]), grads[k], dbias=grads[k + 1])
+                ops.gemm([(_cols(ge, sl[t]), None, params[k])], _cols(gn, sl[t]), b_trans=False, mask=_cols(h_prev, sl[t]))
             ge = gn
         dP, dQ = ops.edge_combine_bwd_pq(ge, pack)
         dx = _empty(N, H, x)
@@ -498,11 +508,11 @@ class PNAConvFn(torch.autograd.Function):
             k0 = pidx(t, "pre", 0)
             W0, dW0 = params[k0], grads[k0]
             kp = pidx(t, "post", 0)
-            xt = x[:, sl[t]]
-            ops.queue_wgrad(dP[:, sl[t]], xt, dW0[:, 0:F])
-            ops.queue_wgrad(dQ[:, sl[t]], xt, dW0[:, F:2 * F])
-            ops.gemm([(g[:, sl[t]], None, params[kp][:, 0:F]), (dP[:, sl[t]], None, W0[:, 0:F]),
-                      (dQ[:, sl[t]], None, W0[:, F:2 * F])], dx[:, sl[t]], b_trans=False)
+            xt = _cols(x, sl[t])
+            ops.queue_wgrad(_cols(dP, sl[t]), xt, dW0[:, 0:F])
+            ops.queue_wgrad(_cols(dQ, sl[t]), xt, dW0[:, F:2 * F])
+            ops.gemm([(_cols(g, sl[t]), None, params[kp][:, 0:F]), (_cols(dP, sl[t]), None, W0[:, 0:F]),
+                      (_cols(dQ, sl[t]), None, W0[:, F:2 * F])], _cols(dx, sl[t]), b_trans=False)
         # Bond-table gradient chain: dTe (by-code segment sum over the 84 MB message gradient) -> the edge slice of
         # pre-layer 0 -> edge_encoder -> the bond-embedding gradient.  Nothing on the way to dx depends on it, so it runs
         # on side stream 1 (forked here, i.e. behind the kernel that produced ``ge``) and leaves the critical path.
@@ -516,8 +526,8 @@ class PNAConvFn(torch.autograd.Function):
             dEE = _empty(R, F, x)
             for t in range(T):
                 k0 = pidx(t, "pre", 0)
-                ops.gemm_wgrad_inline(dTe[:, sl[t]], EE, grads[k0][:, 2 * F:3 * F], dbias=grads[k0 + 1])
-                ops.gemm([(dTe[:, sl[t]], None, params[k0][:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
+                ops.gemm_wgrad_inline(_cols(dTe, sl[t]), EE, grads[k0][:, 2 * F:3 * F], dbias=grads[k0 + 1])
+                ops.gemm([(_cols(dTe, sl[t]), None, params[k0][:, 2 * F:3 * F])], dEE, b_trans=False, accumulate=t > 0)
             ops.gemm_wgrad_inline(dEE, BE, d_enc_w, dbias=d_enc_b)
             if acc is None:
                 dBE_box.append(ops.gemm([(dEE, None, enc_w)], _empty(R, H, x), b_trans=False))

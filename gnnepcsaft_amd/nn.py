@@ -183,13 +183,24 @@ class PNAConv(Module):
         self.lin = Linear(out_channels, out_channels)
 
     def _params(self):
+        """The layer's parameters in PNAConvFn's order.  Cached: Parameter objects keep their identity across ``.to()``
+        / ``load_state_dict`` (only ``.data`` changes), and Module.__getattr__ is slow enough to matter here (the hot
+        loop is host-bound at small batches)."""
+        cached = self.__dict__.get("_params_cache")
+        if cached is not None and all(a is b for a, b in zip(cached[1], self._parameter_ids())):
+            return cached[0]
         params = [self.edge_encoder.weight, self.edge_encoder.bias, self.lin.weight, self.lin.bias]
         for t in range(self.towers):
             for lin in self.pre_nns[t].linears():
                 params += [lin.weight, lin.bias]
             for lin in self.post_nns[t].linears():
                 params += [lin.weight, lin.bias]
+        self.__dict__["_params_cache"] = (params, self._parameter_ids())
         return params
+
+    def _parameter_ids(self):
+        # two cheap identity probes: a re-registered parameter (rare: module surgery) invalidates the cache
+        return (self.edge_encoder._parameters["weight"], self.lin._parameters["weight"])
 
     def prepare_ahead(self, edge_index: GraphPack, edge_attr: torch.Tensor) -> "Fn.WeightOnlyAhead":
         """Issue this layer's weight-only work (bond-table chain, Weff(d), merged lin o last post layer) on the side

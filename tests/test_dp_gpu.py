@@ -106,10 +106,12 @@ def test_rccl_exchange_path_with_one_rank(gpu_device):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "3",
-                        "--warmup", "2", "--batch", "512", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                       timeout=500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["n_gpus"] == 1 and out["config"]["grad_allreduce_bytes"] == 2204931 * 4
-    assert "per-layer slices" in out["config"]["grad_exchange"] and out["loss"] == out["loss"]
+    for launch, expect in (("eager", "per-layer slices"), ("graph", "one call after backward")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "3",
+                            "--warmup", "2", "--batch", "512", "--no-cpu-baseline", "--launch", launch], env=env,
+                           capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["n_gpus"] == 1 and out["config"]["grad_allreduce_bytes"] == 2204931 * 4
+        assert expect in out["config"]["grad_exchange"] and out["loss"] == out["loss"], out["config"]
+        assert out["config"]["hip_graph"] == (launch == "graph")

@@ -1,47 +1,38 @@
-"""cProfile of the host side of eager steps (launch path), cfg-2 sizes: where the CPU time per launch goes."""
-import cProfile, os, pstats, sys, io
+"""cProfile of the Python side of one training step (host-bound regime: 512 graphs).  Prints the top functions by
+cumulative and by own time.  usage: python tools/host_profile.py [graphs]"""
+import cProfile, os, pstats, sys, time, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gnnepcsaft_amd import functional as Fn, ops
-from gnnepcsaft_amd.data import default_config, synthetic_batch
-from gnnepcsaft_amd.data.batching import calc_deg
+from gnnepcsaft_amd import dp, functional as Fn, ops
+from gnnepcsaft_amd.data import calc_deg, default_config, synthetic_batch
 from gnnepcsaft_amd.train.models import create_model
-from gnnepcsaft_amd import dp
-
+graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda:0")
+st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 cfg = default_config(2)
-batch = synthetic_batch(int(os.environ.get("GRAPHS", "4096")), 2)
-deg = calc_deg([batch])
+b_cpu = synthetic_batch(graphs, 2); deg = calc_deg(b_cpu)
 torch.manual_seed(0)
-model = create_model(cfg, deg).to(dev)
-model.train()
-model.model.validate_inputs = False
-flat = dp.FlatGradAllReduce(model)
-Fn.set_grad_in_place(True)
-ops.set_wgrad_side_stream(True)
-b = batch.to(dev)
-s = torch.cuda.Stream()
-torch.cuda.set_stream(s)
+model = create_model(cfg, deg).to(dev).train()
+model.model.validate_inputs = False; model.model.max_degree_hint = len(deg) - 1
+flat = dp.FlatGradAllReduce(model); Fn.set_grad_in_place(True); ops.set_wgrad_side_stream(True)
+b = b_cpu.to(dev)
 def step():
-    flat.zero_grad()
-    b._gnx_pack = None
-    loss = model.training_step(b, 0)
-    loss.backward()
-for _ in range(5): step()
+    flat.zero_grad(); b._gnx_pack = None
+    model.training_step(b, 0).backward()
+for _ in range(10): step()
 torch.cuda.synchronize()
-import time
 t0 = time.perf_counter()
-for _ in range(20): step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"host issue time/step {(t1-t0)/20*1e3:.2f} ms, incl. drain {(t2-t0)/20*1e3:.2f} ms")
-pr = cProfile.Profile()
-with torch.autograd.set_multithreading_enabled(False):
-    pr.enable()
-    for _ in range(20): step()
-    pr.disable()
-torch.cuda.synchronize()
-st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(45)
-print(st.getvalue()[:9000])
+for _ in range(50): step()
+torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 50 * 1e3)
+# forward-only host time and backward host time
+t0 = time.perf_counter()
+for _ in range(50):
+    flat.zero_grad(); b._gnx_pack = None
+    loss = model.training_step(b, 0)
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print("host ms for zero_grad+pack+forward (async):", (t1 - t0) / 50 * 1e3)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(30): step()
+pr.disable(); torch.cuda.synchronize()
+for key in ("cumulative", "tottime"):
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28); print(s.getvalue()[:6000])
