@@ -47,6 +47,24 @@ class WgradProb(C.Structure):
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
+PNA_MAX_LAYERS, PNA_MAX_TOWERS = 8, 8
+
+
+class PnaBwdArgs(C.Structure):
+    """gnx_pna_bwd_args of include/gnx.h (same field order)."""
+    _fields_ = [("N", _i64), ("E", _i64), ("T", _i32), ("F", _i32), ("pre_layers", _i32), ("post_layers", _i32),
+                ("R", _i32), ("D", _i32), ("avg_deg_log", _f32), ("merged", _i32), ("acc_first", _i32),
+                ("use_side_streams", _i32), ("n_h", _i32), ("n_z", _i32),
+                ("rowptr", _vp), ("colptr", _vp), ("cpos", _vp), ("code", _vp), ("code_pos", _vp), ("dperm", _vp),
+                ("tiles", _vp), ("ntiles", _vp), ("chunks", _vp), ("nchunks", _vp),
+                ("max_tiles", _i64), ("max_chunks", _i64),
+                ("x", _vp), ("BE", _vp), ("EE", _vp), ("A", _vp),
+                ("hs", _vp * PNA_MAX_LAYERS), ("zs", _vp * PNA_MAX_LAYERS), ("weff", _vp * PNA_MAX_TOWERS), ("Wm", _vp),
+                ("params", C.POINTER(_vp)), ("grads", C.POINTER(_vp)), ("dout", _vp),
+                ("gbuf", _vp * PNA_MAX_LAYERS), ("dA", _vp), ("gebuf", _vp * PNA_MAX_LAYERS), ("dP", _vp), ("dQ", _vp),
+                ("dTe", _vp), ("dEE", _vp), ("dWm", _vp), ("dbm", _vp), ("dWeff", _vp), ("ws", _vp), ("ws_bytes", _sz),
+                ("acc_buf", _vp), ("dx", _vp)]
+
 # every symbol include/gnx.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "gnx_create": (_i32, [C.POINTER(_vp), _i32]),
@@ -104,6 +122,8 @@ SIGNATURES = {
     "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gnx_adamw_amsgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "gnx_sgd": (_i32, [_vp, _vp, _vp, _i64, _f32]),
+    "gnx_pna_conv_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "gnx_pna_conv_bwd": (_i32, [_vp, C.POINTER(PnaBwdArgs)]),
     "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),
     "gnx_scale": (_i32, [_vp, _vp, _i64, _f32]),
     "gnx_axpy": (_i32, [_vp, _vp, _vp, _i64, _f32]),

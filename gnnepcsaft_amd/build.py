@@ -16,7 +16,7 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libgnnepcsaft_hip.so"
 OBJ_DIR = PKG / "csrc" / "build"
-SOURCES = ["gnx_api.hip", "gnx_pack.hip", "gnx_embed.hip", "gnx_gemm.hip", "gnx_aggregate.hip", "gnx_norm.hip", "gnx_optim.hip"]
+SOURCES = ["gnx_api.hip", "gnx_pack.hip", "gnx_embed.hip", "gnx_gemm.hip", "gnx_aggregate.hip", "gnx_norm.hip", "gnx_optim.hip", "gnx_layer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{CSRC}"]
 

@@ -1,0 +1,217 @@
+// Native launch sequence of one PNAConv backward (gnx_pna_conv_bwd): the ~35 launches that
+// gnnepcsaft_amd/functional.py::PNAConvFn.backward issues one by one from Python (0.32 ms of host time per layer, 5.5 ms
+// per cfg-2 step, against 7.9 ms of GPU time) are issued here from ONE call -- same kernels, same streams, same order.
+// It only composes the public entry points of gnx.h; nothing below touches a kernel directly.
+//
+// Reference semantics: the backward of [3P] torch_geometric.nn.PNAConv as built at
+// /root/reference/gnnepcsaft/train/models.py:445-457 (restructured as DESIGN.md §4 describes: node-level P/Q products +
+// 60-row bond table for pre-layer 0, per-degree-class effective weights for post-layer 0, lin o last post layer merged).
+#include "gnx_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+inline gnx_gemm_seg seg(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t k) {
+  gnx_gemm_seg s;
+  s.a = a;
+  s.lda = lda;
+  s.rowscale = nullptr;
+  s.b = b;
+  s.ldb = ldb;
+  s.k = k;
+  s._pad = 0;
+  return s;
+}
+
+struct WgradQueue {
+  std::vector<gnx_wgrad_prob> q;
+  void add(const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M, int32_t N, int32_t K, float* dW,
+           int64_t lddw, float* dbias) {
+    if (M <= 0) return;
+    gnx_wgrad_prob p;
+    p.dC = dC;
+    p.lddc = lddc;
+    p.A = A;
+    p.lda = lda;
+    p.rowscale = nullptr;
+    p.dW = dW;
+    p.lddw = lddw;
+    p.dbias = dbias;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    q.push_back(p);
+  }
+  // up to 8 problems per launch, largest row counts first (problems of similar size share a launch)
+  int32_t flush(gnx_handle* h) {
+    std::stable_sort(q.begin(), q.end(), [](const gnx_wgrad_prob& a, const gnx_wgrad_prob& b) { return a.M > b.M; });
+    for (size_t i = 0; i < q.size(); i += 8) {
+      const int32_t n = (int32_t)std::min<size_t>(8, q.size() - i);
+      const int32_t st = gnx_gemm_wgrad_batched(h, n, q.data() + i);
+      if (st != GNX_OK) return st;
+    }
+    q.clear();
+    return GNX_OK;
+  }
+};
+
+#define GNX_TRY(call)                 \
+  do {                                \
+    const int32_t st_ = (call);       \
+    if (st_ != GNX_OK) return st_;    \
+  } while (0)
+
+// runs `body` on side stream `which` (forked from the current point of the bound stream), restoring the stream on any exit
+template <class F>
+int32_t on_side(gnx_handle* h, int which, bool enabled, F body) {
+  if (!enabled) return body();
+  GNX_TRY(gnx_side_begin_n(h, which));
+  const int32_t st = body();
+  (void)gnx_side_end(h);
+  return st;
+}
+
+}  // namespace
+
+// upper bound of the split-weight images any product of the layer's backward needs (gnx_gemm_workspace_bytes): the
+// degree-class product dA = g Weff(d) (D classes, N = 4F, K = F) and the 3-segment dx product (N = F, K = 3F)
+extern "C" size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D) {
+  auto pad = [](int64_t v, int64_t m) { return (v + m - 1) / m * m; };
+  const size_t grouped = (size_t)(D > 0 ? D : 1) * 3 * pad(4 * (int64_t)F, 128) * pad(F, 32) * 2;
+  const size_t dx = (size_t)3 * pad(F, 128) * (3 * pad(F, 32)) * 2;
+  const size_t lin = (size_t)3 * pad((int64_t)T * F, 128) * pad((int64_t)T * F, 32) * 2;  // lin / merged product, H x H
+  return std::max(grouped, std::max(dx, lin)) + 256;
+}
+
+extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
+  GNX_CHECK_ARG(h && a, "gnx_pna_conv_bwd: NULL argument");
+  const int T = a->T, F = a->F, pre = a->pre_layers, post = a->post_layers, R = a->R, D = a->D;
+  const int64_t N = a->N, E = a->E;
+  const int H = T * F;
+  GNX_CHECK_ARG(T >= 1 && F >= 1 && pre >= 1 && pre <= GNX_PNA_MAX_LAYERS && post >= 1 && post <= GNX_PNA_MAX_LAYERS &&
+                    T <= GNX_PNA_MAX_TOWERS && D >= 1 && R >= 1,
+                "gnx_pna_conv_bwd: bad layer shape T=%d F=%d pre=%d post=%d D=%d R=%d", T, F, pre, post, D, R);
+  GNX_CHECK_ARG(a->params && a->grads && a->dout && a->x && a->A && a->dx && a->acc_buf, "gnx_pna_conv_bwd: NULL array");
+  const bool side = a->use_side_streams != 0;
+  const int per = 2 * (pre + post);
+  auto pidx = [&](int t, bool is_pre, int i) { return 4 + t * per + 2 * (is_pre ? i : pre + i); };
+  const float* const* P = a->params;
+  float* const* G = a->grads;
+  const float* lin_w = P[2];
+  WgradQueue wq;
+
+  // ---- lin (or lin o last post layer): dgrad into gbuf[0]
+  // every gradient buffer of the chain is distinct: the queued weight-gradient problems read them at flush time
+  int gi = 0;
+  float* g = a->gbuf[gi];
+  const float* z_last = a->zs[a->n_z - 1];
+  int last_hidden;
+  if (a->merged) {
+    GNX_TRY(gnx_fill(h, a->dWm, (int64_t)H * H, 0.f));
+    GNX_TRY(gnx_fill(h, a->dbm, H, 0.f));
+    wq.add(a->dout, H, z_last, H, N, H, H, a->dWm, H, a->dbm);
+    gnx_gemm_seg s = seg(a->dout, H, a->Wm, H, H);
+    GNX_TRY(gnx_gemm(h, 1, &s, N, H, nullptr, z_last, H, g, H, 0, a->ws, a->ws_bytes));
+    last_hidden = post - 2;
+  } else {
+    wq.add(a->dout, H, z_last, H, N, H, H, G[2], H, G[3]);
+    gnx_gemm_seg s = seg(a->dout, H, lin_w, H, H);
+    GNX_TRY(gnx_gemm(h, 1, &s, N, H, nullptr, nullptr, 0, g, H, 0, a->ws, a->ws_bytes));
+    last_hidden = post - 1;
+  }
+  // ---- hidden post layers last..1: dgrad masked by the relu'd input activation
+  for (int i = last_hidden; i >= 1; --i) {
+    const float* a_prev = a->zs[i - 1];
+    for (int t = 0; t < T; ++t) {
+      const int k = pidx(t, false, i);
+      wq.add(g + t * F, H, a_prev + t * F, H, N, F, F, G[k], F, G[k + 1]);
+      gnx_gemm_seg s = seg(g + t * F, H, P[k], F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s, N, F, nullptr, a_prev + t * F, H, a->gbuf[gi + 1] + t * F, H, 0, a->ws, a->ws_bytes));
+    }
+    g = a->gbuf[++gi];
+  }
+  // ---- post layer 0: x-part weight gradient (queued), per-class weight gradient (side stream 0), dA
+  for (int t = 0; t < T; ++t) {
+    const int k = pidx(t, false, 0);
+    const float* gt = g + t * F;
+    const float* At = a->A + (int64_t)t * 4 * F;
+    float* dWp = G[k];
+    wq.add(gt, H, a->x + t * F, H, N, F, F, dWp, 13 * F, G[k + 1]);
+    float* dWeff = a->dWeff + (int64_t)t * D * F * 4 * F;
+    GNX_TRY(gnx_fill(h, dWeff, (int64_t)D * F * 4 * F, 0.f));
+    GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
+      GNX_TRY(gnx_gemm_wgrad_grouped(h, gt, H, At, (int64_t)T * 4 * F, N, F, 4 * F, dWeff, 4 * F, (int64_t)F * 4 * F, a->dperm,
+                                     a->chunks, a->nchunks, a->max_chunks));
+      return gnx_pna_weff_bwd(h, dWeff, F, D, a->avg_deg_log, dWp, 13 * F);
+    }));
+    gnx_gemm_seg s = seg(gt, H, a->weff[t], 4 * F, F);
+    const int64_t stride = (int64_t)4 * F * F;
+    GNX_TRY(gnx_gemm_grouped(h, 1, &s, &stride, D, N, 4 * F, nullptr, nullptr, 0, a->dA + (int64_t)t * 4 * F,
+                             (int64_t)T * 4 * F, 0, a->dperm, a->tiles, a->ntiles, a->max_tiles, a->ws, a->ws_bytes));
+  }
+  const float* g_post0 = g;  // gradient w.r.t. post-layer 0's output: also an operand of dx below
+  // ---- scatter-aggregate backward, then the pre layers last..1
+  int ei = 0;
+  float* ge = a->gebuf[ei];
+  GNX_TRY(gnx_pna_aggregate_bwd(h, a->dA, a->hs[a->n_h - 1], a->A, a->rowptr, N, E, T, F, ge));
+  for (int i = pre - 1; i >= 1; --i) {
+    const float* h_prev = a->hs[i - 1];
+    for (int t = 0; t < T; ++t) {
+      const int k = pidx(t, true, i);
+      wq.add(ge + t * F, H, h_prev + t * F, H, E, F, F, G[k], F, G[k + 1]);
+      gnx_gemm_seg s = seg(ge + t * F, H, P[k], F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s, E, F, nullptr, h_prev + t * F, H, a->gebuf[ei + 1] + t * F, H, 0, a->ws, a->ws_bytes));
+    }
+    ge = a->gebuf[++ei];
+  }
+  // ---- message assembly backward: dP, dQ; input gradient
+  GNX_TRY(gnx_edge_combine_bwd(h, ge, a->rowptr, a->colptr, a->cpos, a->code, N, E, H, 0, a->dP, a->dQ, nullptr, nullptr, 0));
+  for (int t = 0; t < T; ++t) {
+    const int k0 = pidx(t, true, 0), kp = pidx(t, false, 0);
+    const float* W0 = P[k0];
+    float* dW0 = G[k0];
+    wq.add(a->dP + t * F, H, a->x + t * F, H, N, F, F, dW0, 3 * F, nullptr);
+    wq.add(a->dQ + t * F, H, a->x + t * F, H, N, F, F, dW0 + F, 3 * F, nullptr);
+    gnx_gemm_seg s3[3] = {seg(g_post0 + t * F, H, P[kp], 13 * F, F), seg(a->dP + t * F, H, W0, 3 * F, F),
+                          seg(a->dQ + t * F, H, W0 + F, 3 * F, F)};
+    GNX_TRY(gnx_gemm(h, 3, s3, N, F, nullptr, nullptr, 0, a->dx + t * F, H, 0, a->ws, a->ws_bytes));
+  }
+  // ---- bond-table gradient chain on side stream 1 (feeds parameter gradients and the shared accumulator only)
+  GNX_TRY(on_side(h, 1, side, [&]() -> int32_t {
+    GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
+    if (E > 0) GNX_TRY(gnx_key_segment_sum(h, ge, a->code_pos, a->code, E, H, a->dTe));
+    for (int t = 0; t < T; ++t) {
+      const int k0 = pidx(t, true, 0);
+      GNX_TRY(gnx_gemm_wgrad(h, a->dTe + t * F, H, a->EE, F, nullptr, R, F, F, G[k0] + 2 * F, 3 * F, G[k0 + 1]));
+      gnx_gemm_seg s = seg(a->dTe + t * F, H, P[k0] + 2 * F, 3 * F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s, R, F, nullptr, nullptr, 0, a->dEE, F, t > 0 ? GNX_GEMM_ACCUMULATE : 0, nullptr, 0));
+    }
+    GNX_TRY(gnx_gemm_wgrad(h, a->dEE, F, a->BE, H, nullptr, R, F, H, G[0], H, G[1]));
+    if (a->acc_first) GNX_TRY(gnx_fill(h, a->acc_buf, (int64_t)R * H, 0.f));
+    gnx_gemm_seg s = seg(a->dEE, F, P[0], H, F);
+    return gnx_gemm(h, 1, &s, R, H, nullptr, nullptr, 0, a->acc_buf, H, GNX_GEMM_ACCUMULATE, nullptr, 0);
+  }));
+  // ---- the layer's weight gradients in batched launches on side stream 0, then what hangs off dWm
+  GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
+    GNX_TRY(wq.flush(h));
+    if (!a->merged) return GNX_OK;
+    const float* dbm = a->dbm;
+    for (int t = 0; t < T; ++t) {
+      const int k = pidx(t, false, post - 1);
+      const float* Wt = P[k];
+      const float* bt = P[k + 1];
+      // d lin_w[:, t] += dWm[:, t] W_t^T + dbm b_t^T ; dW_t += lin_w[:, t]^T dWm[:, t] ; db_t += dbm lin_w[:, t]
+      gnx_gemm_seg s1 = seg(a->dWm + t * F, H, Wt, F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s1, H, F, nullptr, nullptr, 0, G[2] + t * F, H, GNX_GEMM_ACCUMULATE | GNX_GEMM_B_TRANS, nullptr, 0));
+      gnx_gemm_seg s2 = seg(dbm, 1, bt, 1, 1);
+      GNX_TRY(gnx_gemm(h, 1, &s2, H, F, nullptr, nullptr, 0, G[2] + t * F, H, GNX_GEMM_ACCUMULATE | GNX_GEMM_B_TRANS, nullptr, 0));
+      GNX_TRY(gnx_gemm_wgrad(h, lin_w + t * F, H, a->dWm + t * F, H, nullptr, H, F, F, G[k], F, nullptr));
+      gnx_gemm_seg s3 = seg(dbm, H, lin_w + t * F, H, H);
+      GNX_TRY(gnx_gemm(h, 1, &s3, 1, F, nullptr, nullptr, 0, G[k + 1], F, GNX_GEMM_ACCUMULATE, nullptr, 0));
+    }
+    return gnx_axpy(h, G[3], dbm, H, 1.0f);
+  }));
+  return GNX_OK;
+}

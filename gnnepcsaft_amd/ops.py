@@ -557,6 +557,21 @@ def run_after_wgrads(ref: torch.Tensor, tensors, fn) -> None:
     _run_on_side(ref, tensors, fn)
 
 
+def keep_until_join(device: torch.device, tensors, whichs=(0, 1)) -> None:
+    """Register buffers that launches issued on the side streams by a native composite call (gnx_pna_conv_bwd) read or
+    write: they stay referenced until the join, exactly like the operands of ``_run_on_side``."""
+    if not _SIDE_ENABLED:
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    _SIDE_KEEP.setdefault(idx, []).extend(t for t in tensors if t is not None)
+    _SIDE_PENDING.add(idx)
+    _SIDE_USED.setdefault(idx, set()).update(whichs)
+
+
+def pna_conv_bwd(args: "_lib.PnaBwdArgs", device: torch.device) -> None:
+    check(_lib.load().gnx_pna_conv_bwd(handle(device), C.byref(args)))
+
+
 def run_on_second_side_stream(ref: torch.Tensor, tensors, fn) -> None:
     """Run ``fn`` on side stream 1 (inline when side streams are off): the bond-table gradient chain of a conv layer's
     backward -- it forks from the main stream here, feeds parameter gradients and the bond-embedding gradient only, and

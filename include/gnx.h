@@ -324,6 +324,54 @@ int32_t gnx_adamw_amsgrad(gnx_handle* h, float* p, const float* g, float* m, flo
 /* torch.optim.SGD(momentum=0, weight_decay=0, nesterov=False): p -= lr * g */
 int32_t gnx_sgd(gnx_handle* h, float* p, const float* g, int64_t n, float lr);
 
+/* ---- one conv layer's backward as ONE call (native launch sequence) ------------------------------------------- */
+/* The backward of PNAConv (ref: train/models.py:445-457 via autograd) is ~35 launches; issued one by one from Python
+ * they cost 0.3 ms of host time per layer.  gnx_pna_conv_bwd issues the same launches in the same order on the same
+ * streams (bound stream; side stream 0 = weight gradients; side stream 1 = bond-table chain) from one call.  Every
+ * pointer is caller-owned device memory except `params` / `grads`, HOST arrays of 4 + T*2*(pre+post) device pointers in
+ * the order: edge_encoder.{weight,bias}, lin.{weight,bias}, then per tower pre_nns (w, b) x pre_layers and post_nns
+ * (w, b) x post_layers.  All gradients are ACCUMULATED (+=) into `grads` (persistent in-place sinks).  Requires the
+ * degree-class form of post-layer 0 (D classes, tables from gnx_degree_classes / gnx_class_tiles with 128-row tiles
+ * and the weight-gradient chunks) and the by-code inverted index code_pos (gnx_group_by_small_key). */
+#define GNX_PNA_MAX_LAYERS 8
+#define GNX_PNA_MAX_TOWERS 8
+typedef struct {
+  int64_t N, E;
+  int32_t T, F, pre_layers, post_layers, R, D;
+  float avg_deg_log;
+  int32_t merged;            /* 1: lin o last post layer was evaluated as one product with Wm (post_layers > 1) */
+  int32_t acc_first;         /* 1: this layer's backward is the first of the pass: clear acc_buf before adding */
+  int32_t use_side_streams;  /* 0: everything on the bound stream */
+  int32_t n_h, n_z;          /* number of saved pre activations hs[] (= pre_layers) and post activations zs[] */
+  /* graph structure (gnx_pack_csr, gnx_degree_classes, gnx_class_tiles, gnx_group_by_small_key) */
+  const int32_t *rowptr, *colptr, *cpos, *code, *code_pos, *dperm, *tiles, *ntiles, *chunks, *nchunks;
+  int64_t max_tiles, max_chunks;
+  /* saved by the forward */
+  const float *x, *BE, *EE, *A;               /* [N,H], [R,H], [R,F], [N,T*4F] */
+  const float* hs[GNX_PNA_MAX_LAYERS];        /* [E,H] each; hs[n_h-1] = the messages */
+  const float* zs[GNX_PNA_MAX_LAYERS];        /* [N,H] each */
+  const float* weff[GNX_PNA_MAX_TOWERS];      /* [D,F,4F] per tower */
+  const float* Wm;                            /* [H,H] merged weight (merged = 1) */
+  const float* const* params;                 /* HOST array of device pointers */
+  float* const* grads;                        /* HOST array of device pointers (accumulated) */
+  const float* dout;                          /* [N,H] upstream gradient */
+  /* temporaries, caller-allocated, contents undefined on entry */
+  float* gbuf[GNX_PNA_MAX_LAYERS];            /* [N,H] each: post_layers of them (every level of the gradient chain
+                                                 keeps its own buffer: queued weight gradients read them later) */
+  float* dA;                                  /* [N,T*4F] */
+  float* gebuf[GNX_PNA_MAX_LAYERS];           /* [E,H] each: pre_layers of them */
+  float *dP, *dQ;                             /* [N,H] */
+  float *dTe, *dEE;                           /* [R,H], [R,F] */
+  float *dWm, *dbm;                           /* [H,H], [H] (merged = 1) */
+  float* dWeff;                               /* [T,D,F,4F] */
+  void* ws;                                   /* split weight images: >= gnx_pna_conv_bwd_workspace_bytes */
+  size_t ws_bytes;
+  float* acc_buf;                             /* [R,H] bond-embedding gradient accumulator shared by the model's layers */
+  float* dx;                                  /* [N,H] out: gradient w.r.t. the layer input */
+} gnx_pna_bwd_args;
+size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D);
+int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* args);
+
 /* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
 int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
 /* p[i] *= v : the 1/world factor of the gradient average after the all-reduce (sum) of the flat gradient buffer

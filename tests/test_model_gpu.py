@@ -228,3 +228,48 @@ def test_side_stream_without_in_place_sinks_equals_inline(gpu_device, conv):
         ops.set_wgrad_side_stream(False)
     assert not ops._SIDE_PENDING and not ops._SIDE_KEEP
     assert rel_err(flat.flat, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("kw,graphs,gen", [
+    (dict(hidden_dim=128, propagation_depth=3), 512, 2),                                    # large-batch kernels, merged lin
+    (dict(hidden_dim=128, towers=4, propagation_depth=2), 64, 5),                           # towers, skewed degrees
+    (dict(hidden_dim=32, pre_layers=1, post_layers=1, propagation_depth=2), 32, 2),          # no hidden layers, no merge
+    (dict(hidden_dim=48, pre_layers=3, post_layers=2, propagation_depth=2, dropout=0.2), 32, 2),
+])
+def test_native_layer_backward_equals_the_python_launch_sequence(gpu_device, kw, graphs, gen):
+    """gnx_pna_conv_bwd (one native call per layer) issues the launches PNAConvFn.backward issues from Python: same
+    loss, same input path, same flat gradient (up to the fp32 atomics' order) -- with and without side streams."""
+    from gnnepcsaft_amd import dp, functional as Fn, ops
+    from gnnepcsaft_amd.data import calc_deg, synthetic_batch
+    from gnnepcsaft_amd.train.models import create_model
+    cfg = _cfg(**kw)
+    batch = synthetic_batch(graphs, gen)
+    deg = calc_deg(batch)
+    b = batch.to("cuda:0")
+    results = {}
+    try:
+        Fn.set_grad_in_place(True)
+        for native in (True, False):
+            for side in (True, False):
+                torch.manual_seed(0)
+                m = create_model(copy.deepcopy(cfg), deg).to("cuda:0").train()
+                m.model.max_degree_hint = len(deg) - 1
+                flat = dp.FlatGradAllReduce(m)
+                Fn.set_native_layer_backward(native)
+                ops.set_wgrad_side_stream(side)
+                for _ in range(2):
+                    flat.zero_grad()
+                    b._gnx_pack = None
+                    m.model.dropout.calls = 0
+                    loss = m.training_step(b, 0)
+                    loss.backward()
+                torch.cuda.synchronize()
+                results[(native, side)] = (float(loss), flat.flat.clone())
+    finally:
+        Fn.set_grad_in_place(False)
+        Fn.set_native_layer_backward(True)
+        ops.set_wgrad_side_stream(False)
+    ref_loss, ref = results[(False, False)]
+    for key, (l, g) in results.items():
+        assert l == ref_loss, key
+        assert rel_err(g, ref) <= 2e-6, (key, rel_err(g, ref))
