@@ -50,6 +50,16 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 PNA_MAX_LAYERS, PNA_MAX_TOWERS = 8, 8
 
 
+class PnaFwdArgs(C.Structure):
+    """gnx_pna_fwd_args of include/gnx.h (same field order)."""
+    _fields_ = [("N", _i64), ("E", _i64), ("T", _i32), ("F", _i32), ("pre_layers", _i32), ("post_layers", _i32),
+                ("D", _i32), ("merged", _i32),
+                ("rowptr", _vp), ("src", _vp), ("dst", _vp), ("code", _vp), ("dperm", _vp), ("tiles", _vp), ("ntiles", _vp),
+                ("max_tiles", _i64), ("x", _vp), ("Te", _vp), ("weff", _vp * PNA_MAX_TOWERS), ("Wm", _vp), ("bm", _vp),
+                ("params", C.POINTER(_vp)), ("P", _vp), ("Q", _vp), ("A", _vp), ("hs", _vp * PNA_MAX_LAYERS),
+                ("zs", _vp * PNA_MAX_LAYERS), ("ws", _vp), ("ws_bytes", _sz), ("out", _vp)]
+
+
 class PnaBwdArgs(C.Structure):
     """gnx_pna_bwd_args of include/gnx.h (same field order)."""
     _fields_ = [("N", _i64), ("E", _i64), ("T", _i32), ("F", _i32), ("pre_layers", _i32), ("post_layers", _i32),
@@ -122,6 +132,9 @@ SIGNATURES = {
     "gnx_huber_ape": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "gnx_adamw_amsgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "gnx_sgd": (_i32, [_vp, _vp, _vp, _i64, _f32]),
+    "gnx_pna_weight_only": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, C.POINTER(_vp), _i32, _vp, _vp,
+                                   C.POINTER(_vp), _vp, _vp]),
+    "gnx_pna_conv_fwd": (_i32, [_vp, C.POINTER(PnaFwdArgs)]),
     "gnx_pna_conv_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "gnx_pna_conv_bwd": (_i32, [_vp, C.POINTER(PnaBwdArgs)]),
     "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),

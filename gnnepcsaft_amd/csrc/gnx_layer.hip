@@ -75,14 +75,16 @@ int32_t on_side(gnx_handle* h, int which, bool enabled, F body) {
 
 }  // namespace
 
-// upper bound of the split-weight images any product of the layer's backward needs (gnx_gemm_workspace_bytes): the
+// upper bound of the split-weight images any product of the layer's forward or backward needs (gnx_gemm_workspace_bytes): the
 // degree-class product dA = g Weff(d) (D classes, N = 4F, K = F) and the 3-segment dx product (N = F, K = 3F)
 extern "C" size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D) {
   auto pad = [](int64_t v, int64_t m) { return (v + m - 1) / m * m; };
   const size_t grouped = (size_t)(D > 0 ? D : 1) * 3 * pad(4 * (int64_t)F, 128) * pad(F, 32) * 2;
   const size_t dx = (size_t)3 * pad(F, 128) * (3 * pad(F, 32)) * 2;
   const size_t lin = (size_t)3 * pad((int64_t)T * F, 128) * pad((int64_t)T * F, 32) * 2;  // lin / merged product, H x H
-  return std::max(grouped, std::max(dx, lin)) + 256;
+  // forward: post-layer 0 by degree class, z = x W0^T + A Weff(d)^T  (N = F, K = F + 4F)
+  const size_t post0 = (size_t)(D > 0 ? D : 1) * 3 * pad(F, 128) * (pad(F, 32) + pad(4 * (int64_t)F, 32)) * 2;
+  return std::max(std::max(grouped, post0), std::max(dx, lin)) + 256;
 }
 
 extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
@@ -214,4 +216,91 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     return gnx_axpy(h, G[3], dbm, H, 1.0f);
   }));
   return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-only part of a PNAConv forward (functional._pna_weight_only): EE = BondEmb W_enc^T + b_enc, Te (edge slice of
+// pre-layer 0 on the 60-row bond table), Weff(d) per tower, merged lin o last post layer.  5 + 3(T-1) tiny launches.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t gnx_pna_weight_only(gnx_handle* h, const float* BE, int32_t R, int32_t T, int32_t F, int32_t pre_layers,
+                                       int32_t post_layers, int32_t D, float avg_deg_log, const float* const* params,
+                                       int32_t merged, float* EE, float* Te, float* const* weff, float* Wm, float* bm) {
+  GNX_CHECK_ARG(h && BE && params && EE && Te && R > 0 && T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 1 && pre_layers >= 1 &&
+                    post_layers >= 1, "gnx_pna_weight_only: bad argument");
+  const int H = T * F, per = 2 * (pre_layers + post_layers);
+  gnx_gemm_seg s = seg(BE, H, params[0], H, H);
+  GNX_TRY(gnx_gemm(h, 1, &s, R, F, params[1], nullptr, 0, EE, F, GNX_GEMM_B_TRANS, nullptr, 0));
+  for (int t = 0; t < T; ++t) {
+    const float* W0 = params[4 + t * per];
+    gnx_gemm_seg se = seg(EE, F, W0 + 2 * F, 3 * F, F);
+    GNX_TRY(gnx_gemm(h, 1, &se, R, F, params[4 + t * per + 1], nullptr, 0, Te + t * F, H, GNX_GEMM_B_TRANS, nullptr, 0));
+    if (D > 0) {
+      GNX_CHECK_ARG(weff && weff[t], "gnx_pna_weight_only: weff[%d] is NULL", t);
+      GNX_TRY(gnx_pna_weff(h, params[4 + t * per + 2 * pre_layers], 13 * F, F, D, avg_deg_log, weff[t]));
+    }
+  }
+  if (merged) {
+    GNX_CHECK_ARG(Wm && bm && post_layers > 1, "gnx_pna_weight_only: merged without Wm / bm");
+    const float* lin_w = params[2];
+    for (int t = 0; t < T; ++t) {
+      const int k = 4 + t * per + 2 * (pre_layers + post_layers - 1);
+      gnx_gemm_seg sw = seg(lin_w + t * F, H, params[k], F, F);                        // Wm[:, t] = lin_w[:, t] @ W_last_t
+      GNX_TRY(gnx_gemm(h, 1, &sw, H, F, nullptr, nullptr, 0, Wm + t * F, H, 0, nullptr, 0));
+      gnx_gemm_seg sb = seg(params[k + 1], F, lin_w + t * F, H, F);                    // bm (+)= b_last_t @ lin_w[:, t]^T
+      GNX_TRY(gnx_gemm(h, 1, &sb, 1, H, t == 0 ? params[3] : nullptr, nullptr, 0, bm, H,
+                       GNX_GEMM_B_TRANS | (t > 0 ? GNX_GEMM_ACCUMULATE : 0), nullptr, 0));
+    }
+  }
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward launch sequence of one PNAConv (functional.PNAConvFn.forward after the weight-only part): node-level P / Q
+// products, message assembly, remaining pre layers, scatter-aggregate, post-layer 0 by degree class, hidden post
+// layers, lin (or the merged product).  Every activation the backward needs is written into caller-owned buffers.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
+  GNX_CHECK_ARG(h && a, "gnx_pna_conv_fwd: NULL argument");
+  const int T = a->T, F = a->F, pre = a->pre_layers, post = a->post_layers, D = a->D;
+  const int64_t N = a->N, E = a->E;
+  const int H = T * F;
+  GNX_CHECK_ARG(T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 1 && pre >= 1 && pre <= GNX_PNA_MAX_LAYERS && post >= 1 &&
+                    post <= GNX_PNA_MAX_LAYERS && D >= 1, "gnx_pna_conv_fwd: bad layer shape");
+  GNX_CHECK_ARG(a->params && a->x && a->Te && a->P && a->Q && a->A && a->out, "gnx_pna_conv_fwd: NULL array");
+  const int per = 2 * (pre + post);
+  const float* const* W = a->params;
+  for (int t = 0; t < T; ++t) {
+    const float* W0 = W[4 + t * per];
+    gnx_gemm_seg sp = seg(a->x + t * F, H, W0, 3 * F, F), sq = seg(a->x + t * F, H, W0 + F, 3 * F, F);
+    GNX_TRY(gnx_gemm(h, 1, &sp, N, F, nullptr, nullptr, 0, a->P + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
+    GNX_TRY(gnx_gemm(h, 1, &sq, N, F, nullptr, nullptr, 0, a->Q + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
+  }
+  GNX_TRY(gnx_edge_combine_fwd(h, a->P, a->Q, a->Te, a->src, a->dst, a->code, E, H, pre > 1 ? 1 : 0, a->hs[0]));
+  for (int i = 1; i < pre; ++i)
+    for (int t = 0; t < T; ++t) {
+      const int k = 4 + t * per + 2 * i;
+      gnx_gemm_seg s = seg(a->hs[i - 1] + t * F, H, W[k], F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s, E, F, W[k + 1], nullptr, 0, a->hs[i] + t * F, H,
+                       GNX_GEMM_B_TRANS | (i < pre - 1 ? GNX_GEMM_RELU : 0), a->ws, a->ws_bytes));
+    }
+  GNX_TRY(gnx_pna_aggregate_fwd(h, a->hs[pre - 1], a->rowptr, N, E, T, F, a->A));
+  for (int t = 0; t < T; ++t) {
+    const int k = 4 + t * per + 2 * pre;
+    gnx_gemm_seg s2[2] = {seg(a->x + t * F, H, W[k], 13 * F, F), seg(a->A + (int64_t)t * 4 * F, (int64_t)T * 4 * F, a->weff[t], 4 * F, 4 * F)};
+    const int64_t strides[2] = {0, (int64_t)4 * F * F};
+    GNX_TRY(gnx_gemm_grouped(h, 2, s2, strides, D, N, F, W[k + 1], nullptr, 0, a->zs[0] + t * F, H,
+                             GNX_GEMM_B_TRANS | (post > 1 ? GNX_GEMM_RELU : 0), a->dperm, a->tiles, a->ntiles, a->max_tiles,
+                             a->ws, a->ws_bytes));
+  }
+  const int hidden_end = a->merged ? post - 1 : post;  // hidden layers 1 .. hidden_end-1 are evaluated one by one
+  int zi = 0;
+  for (int i = 1; i < hidden_end; ++i, ++zi)
+    for (int t = 0; t < T; ++t) {
+      const int k = 4 + t * per + 2 * (pre + i);
+      gnx_gemm_seg s = seg(a->zs[zi] + t * F, H, W[k], F, F);
+      GNX_TRY(gnx_gemm(h, 1, &s, N, F, W[k + 1], nullptr, 0, a->zs[zi + 1] + t * F, H,
+                       GNX_GEMM_B_TRANS | (i < post - 1 ? GNX_GEMM_RELU : 0), a->ws, a->ws_bytes));
+    }
+  gnx_gemm_seg sl = a->merged ? seg(a->zs[zi], H, a->Wm, H, H) : seg(a->zs[zi], H, W[2], H, H);
+  return gnx_gemm(h, 1, &sl, N, H, a->merged ? a->bm : W[3], nullptr, 0, a->out, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes);
 }

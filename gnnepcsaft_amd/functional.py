@@ -260,6 +260,24 @@ def _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
     ungrouped): EE = BondEmb W_enc^T + b_enc [R,F];  Te = per tower EE W_e^T + b (the edge part of pre-layer 0 on the
     60-row bond table) [R,H];  Weff(d) per tower;  the merged (lin o last post layer) weight / bias."""
     R, H = BE.size(0), T * F
+    merged = post_layers > 1 and _MERGE_LAST_POST
+    if _NATIVE_LAYER_BWD and BE.is_cuda and T <= 8:
+        # one native call (gnx_pna_weight_only) instead of 5 + 3 (T - 1) launches from Python
+        import ctypes as C
+        from . import _lib
+        EE, Te = _empty(R, F, BE), _empty(R, H, BE)
+        weffs = [torch.empty(D, F, 4 * F, dtype=torch.float32, device=BE.device) for _ in range(T)] if D > 0 else []
+        Wm = _empty(H, H, BE) if merged else None
+        bm = torch.empty(H, dtype=torch.float32, device=BE.device) if merged else None
+        n = len(params)
+        parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])
+        warr = (C.c_void_p * max(T, 1))(*[w.data_ptr() for w in weffs]) if weffs else None
+        ops.check(_lib.load().gnx_pna_weight_only(
+            _lib.handle(BE.device), BE.data_ptr(), R, T, F, pre_layers, post_layers, D, float(avg_deg_log),
+            C.cast(parr, C.POINTER(C.c_void_p)), int(merged), EE.data_ptr(), Te.data_ptr(),
+            None if warr is None else C.cast(warr, C.POINTER(C.c_void_p)), None if Wm is None else Wm.data_ptr(),
+            None if bm is None else bm.data_ptr()))
+        return EE, Te, weffs, Wm, bm
     enc_w, enc_b, lin_w, lin_b = params[:4]
     per = 2 * (pre_layers + post_layers)
     sl = _tower_slices(T, F)
@@ -275,7 +293,7 @@ def _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, D):
         k = 4 + t * per + 2 * (pre_layers + post_layers - 1)
         last.append((params[k], params[k + 1]))
     Wm = bm = None
-    if post_layers > 1 and _MERGE_LAST_POST:
+    if merged:
         Wm, bm = _merge_last_post_with_lin(lin_w, lin_b, last, sl, BE)
     return EE, Te, weffs, Wm, bm
 
@@ -353,6 +371,55 @@ def _unmerge_last_post_and_lin(dWm, dbm, lin_w, d_lin_w, d_lin_b, last, last_bia
         ops.gemm_wgrad_inline(_cols(lin_w, sl[t]), _cols(dWm, sl[t]), dWt)                                   # [H,F]^T [H,F]
         ops.gemm([(row, None, _cols(lin_w, sl[t]))], dbt.view(1, -1), b_trans=False, accumulate=True)    # [1,H] @ [H,F]
     ops.axpy_(d_lin_b, dbm)
+
+
+def _pna_forward_native(ctx, x, BE, pack, cfg, params, dc, prep):
+    """PNAConvFn.forward through gnx_pna_conv_fwd (one call for the ~12 launches after the weight-only part)."""
+    import ctypes as C
+    from . import _lib
+    T, F, pre_layers, post_layers, avg_deg_log = cfg[:5]
+    EE, Te, weffs, Wm, bm = prep
+    N, H = x.shape
+    E, D = pack.E, dc.D
+    dev = x.device
+    merged = Wm is not None
+    n_z = post_layers - 1 if merged else post_layers
+    f32 = dict(dtype=torch.float32, device=dev)
+    PQ = torch.empty(2, N, H, **f32)
+    hs_all = torch.empty(pre_layers, max(E, 1), H, **f32)
+    zs_all = torch.empty(max(n_z, 1), N, H, **f32)
+    A = torch.empty(N, T * 4 * F, **f32)
+    out = torch.empty(N, H, **f32)
+    lib = _lib.load()
+    ws_bytes = lib.gnx_pna_conv_bwd_workspace_bytes(T, F, D)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a = _lib.PnaFwdArgs()
+    a.N, a.E, a.T, a.F, a.pre_layers, a.post_layers, a.D, a.merged = N, E, T, F, pre_layers, post_layers, D, int(merged)
+    a.rowptr, a.src, a.dst, a.code = pack.rowptr.data_ptr(), pack.src.data_ptr(), pack.dst.data_ptr(), pack.code.data_ptr()
+    a.dperm, a.tiles, a.ntiles, a.max_tiles = dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(), dc.max_tiles
+    a.x, a.Te = x.data_ptr(), Te.data_ptr()
+    for i, w in enumerate(weffs):
+        a.weff[i] = w.data_ptr()
+    a.Wm, a.bm = (Wm.data_ptr(), bm.data_ptr()) if merged else (None, None)
+    n = len(params)
+    parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])
+    a.params = C.cast(parr, C.POINTER(C.c_void_p))
+    a.P, a.Q, a.A = PQ[0].data_ptr(), PQ[1].data_ptr(), A.data_ptr()
+    hs = [hs_all[i][:E] if E != hs_all.size(1) else hs_all[i] for i in range(pre_layers)]
+    zs = [zs_all[i] for i in range(n_z)]
+    for i, t_ in enumerate(hs):
+        a.hs[i] = t_.data_ptr()
+    for i, t_ in enumerate(zs):
+        a.zs[i] = t_.data_ptr()
+    a.ws, a.ws_bytes, a.out = ws.data_ptr(), ws_bytes, out.data_ptr()
+    ops.check(lib.gnx_pna_conv_fwd(_lib.handle(dev), C.byref(a)))
+    amp, att = pack.degree_scalers(avg_deg_log)
+    ctx.pack, ctx.cfg = pack, cfg[:5]
+    ctx.n_h, ctx.n_z = len(hs), len(zs)
+    ctx.sinks = grad_sinks(params)
+    ctx.dc, ctx.weffs, ctx.Wm = dc, weffs, Wm
+    ctx.save_for_backward(x, BE, EE, A, amp, att, *hs, *zs, *params)
+    return out
 
 
 def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_pos):
@@ -452,6 +519,8 @@ class PNAConvFn(torch.autograd.Function):
         if prep is None:
             prep = _pna_weight_only(BE, T, F, pre_layers, post_layers, avg_deg_log, params, dc.D if dc is not None else 0)
         EE, Te, weffs, Wm, bm = prep
+        if _NATIVE_LAYER_BWD and dc is not None and x.is_cuda and pre_layers <= 8 and post_layers <= 8 and T <= 8:
+            return _pna_forward_native(ctx, x, BE, pack, cfg, params, dc, prep)
         P, Q = _empty(N, H, x), _empty(N, H, x)
         for t in range(T):
             W0 = pre[t][0][0]

@@ -372,6 +372,32 @@ typedef struct {
 size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D);
 int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* args);
 
+/* the weight-only part of a PNAConv forward in one call: EE [R,F], Te [R,H], Weff(d) [D,F,4F] per tower (D > 0) and, with
+ * merged = 1 (post_layers > 1), Wm [H,H] = lin_w @ blockdiag(W_last_t), bm [H] = lin_w b_last + lin_b.  `params` as in
+ * gnx_pna_bwd_args; `weff` a HOST array of T device pointers. */
+int32_t gnx_pna_weight_only(gnx_handle* h, const float* BE, int32_t R, int32_t T, int32_t F, int32_t pre_layers,
+                            int32_t post_layers, int32_t D, float avg_deg_log, const float* const* params, int32_t merged,
+                            float* EE, float* Te, float* const* weff, float* Wm, float* bm);
+/* the rest of the forward in one call.  hs[i] ([E,H], pre_layers of them) and zs[i] ([N,H]: post_layers - merged of
+ * them) are the activations the backward needs; P, Q [N,H] and A [N,T*4F] likewise caller-owned. */
+typedef struct {
+  int64_t N, E;
+  int32_t T, F, pre_layers, post_layers, D, merged;
+  const int32_t *rowptr, *src, *dst, *code, *dperm, *tiles, *ntiles;
+  int64_t max_tiles;
+  const float *x, *Te;                         /* [N,H], [R,H] */
+  const float* weff[GNX_PNA_MAX_TOWERS];
+  const float *Wm, *bm;                        /* merged = 1 */
+  const float* const* params;                  /* HOST array of device pointers */
+  float *P, *Q, *A;
+  float* hs[GNX_PNA_MAX_LAYERS];
+  float* zs[GNX_PNA_MAX_LAYERS];
+  void* ws;                                    /* >= gnx_pna_conv_bwd_workspace_bytes(T, F, D) */
+  size_t ws_bytes;
+  float* out;                                  /* [N,H] */
+} gnx_pna_fwd_args;
+int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* args);
+
 /* ---- small elementwise helpers used by the host module ----------------------------------------------------- */
 int32_t gnx_fill(gnx_handle* h, float* p, int64_t n, float v);
 /* p[i] *= v : the 1/world factor of the gradient average after the all-reduce (sum) of the flat gradient buffer
