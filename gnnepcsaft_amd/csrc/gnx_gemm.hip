@@ -793,6 +793,27 @@ __global__ void __launch_bounds__(256) k_split_weights(split_args g) {
 // wave-specialised variant were all correct and all 3-20 % SLOWER than this two-barrier form; their phase ablations
 // were additive (load + split + MFMA time), i.e. the phases did not overlap inside one workgroup whatever the
 // structure, while two independent workgroups per CU do overlap each other.
+//
+// Round 2 measured the pieces one by one (tools/ubench/*.hip, tools/gemm3_kslope.py, ablations of a software-pipelined
+// rewrite that is NOT in the tree):
+//   * the matrix pipe: 48 bf16 MFMAs take 0.65 us per wave at 2.4 GHz, 0.84-0.87 us with random operands on all 256 CUs
+//     (the power management holds the clock near 1.8 GHz; <= 128 active CUs or constant operands are not throttled);
+//     that is the floor of a K-tile, against 1.5-1.7 us (A inside the Infinity Cache) and 1.85-2.1 us (A streamed from
+//     HBM) that a K-tile costs a CU in this kernel.  A lone workgroup finishes a tile in 34 us, two sharing a CU need
+//     75 us for their two tiles: the second workgroup per CU hides epilogues and tile switches, not the K loop;
+//   * the same wave can overlap its split (VALU) with its MFMAs: 48 MFMAs + the split of 32 floats take 0.78 us where
+//     the parts take 0.65 + 0.60 us;
+//   * a rewrite with one workgroup per CU, ONE barrier per K-tile, the split / LDS stores of K-tile j+2 and the global
+//     loads of K-tile j+4 issued inside the MFMA block of K-tile j, B fragments fetched straight from a fragment-major
+//     weight image into registers (no LDS for B) and a three-stage LDS ring for A reached 1.15 us per K-tile with A in
+//     the Infinity Cache (MFMAs alone 0.75, + LDS fragment reads and loads 1.06, + split and LDS stores 1.15) but
+//     1.8-1.9 us from HBM (the wait for the A loads shows again: four K-tiles of lead are not enough there) and paid
+//     ~20 us more per launch in prologue / epilogues that no second workgroup hides: 111 vs 113-122 us on post-layer 0
+//     (K = 640), 73 vs 69 us on the K = 384 product, 106-110 vs 84-86 us on K = 128 -> N = 512.  Pinning the order of
+//     MFMA groups, fragment reads and LDS stores with sched_barrier, and a 1 x 4 instead of a 2 x 2 wave grid (B read
+//     once per workgroup: L2 serves ~70 GB/s per CU, the Infinity Cache ~33, HBM ~24) did not move these numbers.
+//     Not faster on the shapes of the model, so not kept; what a faster kernel needs is a deeper A prefetch (LDS-DMA)
+//     AND an epilogue that overlaps the next tile, i.e. the structure of the weights-stationary kernel below.
 template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];

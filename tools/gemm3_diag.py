@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnepcsaft_amd import _lib, ops
 dev = torch.device("cuda:0")
-M, F = 81920, 128
+M, F = int(os.environ.get("DIAG_M", "81920")), 128
 x = torch.randn(M, F, device=dev); A = torch.randn(M, 4 * F, device=dev)
 g = torch.randn(M, F, device=dev); dP = torch.randn(M, F, device=dev); dQ = torch.randn(M, F, device=dev)
 Wp = torch.randn(F, 13 * F, device=dev); W0 = torch.randn(F, 3 * F, device=dev)
