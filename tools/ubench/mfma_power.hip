@@ -2,6 +2,8 @@
 //   same      every MFMA of the loop multiplies the same two register fragments (operands never toggle)
 //   rotating  consecutive MFMAs take different fragments (6 A x 6 B random fragments, as in a real K-loop)
 // with small-integer or random significands.  Long runs (tens of ms) so that the power management settles.
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip ; run on the GPU box.
+// MI355X, round 2:  256 CUs constant 0.666 / 0.667 us, random 0.843 / 0.874 us;  128 CUs 0.666-0.674 us in every case.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
