@@ -268,6 +268,7 @@ def main():
     autotune = None
     if args.launch in ("graph", "auto"):
         overlap_was = flat._overlap
+        graph_step = None
         try:
             flat.enable_overlap(False)  # collectives cannot be captured: one exchange after the replay instead
             graph = torch.cuda.CUDAGraph()
@@ -278,11 +279,20 @@ def main():
                 graph.replay()
                 flat.all_reduce()
                 return static_loss
-
+        except Exception as e:  # pylint: disable=broad-except
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            graph_step = None
+        torch.cuda.synchronize()
+        captured = graph_step is not None
+        if dist is not None:  # the exchange pattern differs between the modes: a rank that could not capture takes all with it
+            ok = torch.tensor([1.0 if captured else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            captured = bool(ok.item() > 0.5)
+        use_graph = captured
+        if captured:
             for _ in range(2):
                 graph_step()
             torch.cuda.synchronize()
-            use_graph = True
             if args.launch == "auto":
                 def probe(fn, n=8):
                     torch.cuda.synchronize()
@@ -301,14 +311,10 @@ def main():
                     t_eager, t_graph = float(tt[0]), float(tt[1])
                 use_graph = t_graph < t_eager
                 autotune = {"probe_steps": 8, "eager_ms": t_eager, "graph_ms": t_graph}
-            if use_graph:
-                flat.enable_overlap(False)
-                step, graphed = graph_step, True
-            else:
-                flat.enable_overlap(overlap_was)
-        except Exception as e:  # pylint: disable=broad-except
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
+        if use_graph:
+            flat.enable_overlap(False)
+            step, graphed = graph_step, True
+        else:
             flat.enable_overlap(overlap_was)
             step = eager_step
 

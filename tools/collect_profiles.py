@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_stats(src_dir, dst):
-    f = glob.glob(os.path.join(src_dir, "*", "*_kernel_stats.csv"))
-    if f:
-        shutil.copy(f[0], dst)
+    f = sorted(glob.glob(os.path.join(src_dir, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if f:  # gpurun merges every run's files into the same directory: the newest is this run's
+        shutil.copy(f[-1], dst)
         return True
     return False
 
@@ -39,10 +39,10 @@ def main(tag="r02"):
             shutil.copy(f, os.path.join(prof, f"{tag}_bench_cfg{c}.json"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for which in ("fetch", "write"):
-        fs = glob.glob(os.path.join(src, "pmc", which, "*", "*_counter_collection.csv"))
+        fs = sorted(glob.glob(os.path.join(src, "pmc", which, "*", "*_counter_collection.csv")), key=os.path.getmtime)
         if not fs:
             continue
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(fs[-1])):
             # bench.py also times the scatter kernel on a 16 384-graph batch (roofline.large): keep the cfg-2 launches
             # (81 920 atoms x 32 threads) apart from those
             name = r["Kernel_Name"]
