@@ -539,6 +539,11 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 //     cost of 64 more rows per CU is 4.1 us at every size from 2 to 20 tiles per CU (= 4 TB/s of mixed read + write
 //     traffic), and neither a second tile of loads in flight (hand-counted asm loads) nor software-pipelined fragment
 //     reads moved it; a launch has ~8 us of fixed cost (weight fragments, first tile, drain) on top.
+//     Round 2 (same-box A/B, tools/ws3_scaling.py): two register stages of A loads (tiles t+G and t+2G in flight, 64 KB
+//     per CU) and a branch-free 8-slab loop for K = 128 (the tile's 48 MFMAs and 24 fragment reads in ONE basic block
+//     instead of eight) each changed nothing (25.1 vs 25.2-26.4 us at 81 920 rows, 42-44 vs 40-43 us at 163 840): the
+//     kernel moves 64 KB per 64-row tile and CU in 4.1-4.5 us = 14-16 GB/s per CU of mixed read + write traffic, and
+//     that -- not latency, issue order or the matrix pipe (96 MFMAs per SIMD and tile = 1.3-1.7 us) -- is its bound.
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define W3_BM 64
