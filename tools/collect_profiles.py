@@ -49,6 +49,32 @@ def main(tag="r02"):
             if name.startswith("void k_pna_agg_fwd") and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) != 81920 * 32:
                 name += " [16384-graph batch]"
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # matrix-pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (sum over the 1024 SIMDs of 32 cycles per
+    # v_mfma_f32_32x32x16_bf16) over GRBM_GUI_ACTIVE / 8 (cycles per XCD; rocprofv3 reports the sum over the 8 XCDs)
+    mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    for which, counter in (("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), ("gui", "GRBM_GUI_ACTIVE")):
+        fs = sorted(glob.glob(os.path.join(src, "pmc", which, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+        if not fs:
+            continue
+        for r in csv.DictReader(open(fs[-1])):
+            if r["Counter_Name"] == counter:
+                mf[r["Kernel_Name"]][counter].append(float(r["Counter_Value"]))
+                mf[r["Kernel_Name"]][counter + ".ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    rows = []
+    for k, d in mf.items():
+        b, gu = d.get("SQ_VALU_MFMA_BUSY_CYCLES", []), d.get("GRBM_GUI_ACTIVE", [])
+        if not b or not gu or sum(b) == 0:
+            continue
+        ba, ga = sum(b) / len(b), sum(gu) / len(gu)
+        us = sum(d["GRBM_GUI_ACTIVE.ns"]) / len(gu) / 1e3
+        rows.append((k, len(b), ba, ga, us, ga / 8 / us / 1e3, ba / (1024 * ga / 8)))
+    if rows:
+        with open(os.path.join(prof, f"{tag}_pmc_mfma_busy_per_kernel.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "dispatches", "SQ_VALU_MFMA_BUSY_CYCLES_avg", "GRBM_GUI_ACTIVE_avg", "duration_us_avg",
+                        "clock_GHz(GUI_ACTIVE/8/duration)", "mfma_utilisation(BUSY/(1024*GUI_ACTIVE/8))"])
+            for k, n, ba, ga, us, ghz, util in sorted(rows, key=lambda r: -r[2] * r[1]):
+                w.writerow([k[:90], n, f"{ba:.0f}", f"{ga:.0f}", f"{us:.1f}", f"{ghz:.2f}", f"{util:.3f}"])
     if agg:
         with open(os.path.join(prof, f"{tag}_pmc_fetch_write_per_kernel.csv"), "w", newline="") as fh:
             w = csv.writer(fh)
