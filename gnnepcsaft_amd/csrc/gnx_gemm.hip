@@ -25,6 +25,7 @@
 #include "gnx_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -738,6 +739,7 @@ struct split_args {
   int koff[MAX_SEGS + 1];  // padded k offset of every segment; koff[nseg] = Kpad
   int nseg;
   int N, Npad, Kpad, D;
+  int frag;  // 1: fragment-major blocks [slab][piece][n / 32][lane][8] (k_gemm3p), 0: [piece][128 n][32 k] (k_gemm3)
   __bf16* out;
 };
 
@@ -775,7 +777,18 @@ __global__ void __launch_bounds__(256) k_split_weights(split_args g) {
   split3(x, p1, p2, p3);
   // tile-major: [class][n tile][k tile][piece][128 n][32 k] -> the 24 KB of one (n tile, k tile) are contiguous
   const int NT = g.Npad / BN, KT = g.Kpad / BK;
-  __bf16* o = g.out + ((((int64_t)c * NT + n / BN) * KT + kk / BK) * 3) * (BN * BK) + (n % BN) * BK + (kk % BK);
+  __bf16* blk = g.out + ((((int64_t)c * NT + n / BN) * KT + kk / BK) * 3) * (BN * BK);
+  if (g.frag) {
+    // MFMA B operand of column n, k = 16 slab + 8 half .. +7: lane = 32 half + n % 32 of the (slab, piece, n / 32) fragment
+    const int nl = n % BN, kl2 = kk % BK;
+    const int64_t lane_off = ((int64_t)(nl >> 5) * 64 + ((kl2 >> 3) & 1) * 32 + (nl & 31)) * 8;
+    const int64_t pstride = 4 * 64 * 8, sbase = (int64_t)(kl2 >> 4) * 3 * pstride;
+    *reinterpret_cast<bf16x8*>(blk + sbase + lane_off) = p1;
+    *reinterpret_cast<bf16x8*>(blk + sbase + pstride + lane_off) = p2;
+    *reinterpret_cast<bf16x8*>(blk + sbase + 2 * pstride + lane_off) = p3;
+    return;
+  }
+  __bf16* o = blk + (n % BN) * BK + (kk % BK);
   *reinterpret_cast<bf16x8*>(o) = p1;
   *reinterpret_cast<bf16x8*>(o + BN * BK) = p2;
   *reinterpret_cast<bf16x8*>(o + 2 * BN * BK) = p3;
@@ -808,17 +821,18 @@ __global__ void __launch_bounds__(256) k_split_weights(split_args g) {
 //     75 us for their two tiles: the second workgroup per CU hides epilogues and tile switches, not the K loop;
 //   * the same wave can overlap its split (VALU) with its MFMAs: 48 MFMAs + the split of 32 floats take 0.78 us where
 //     the parts take 0.65 + 0.60 us;
-//   * a rewrite with one workgroup per CU, ONE barrier per K-tile, the split / LDS stores of K-tile j+2 and the global
+//   * a rewrite with ONE workgroup per CU, one barrier per K-tile, the split / LDS stores of K-tile j+2 and the global
 //     loads of K-tile j+4 issued inside the MFMA block of K-tile j, B fragments fetched straight from a fragment-major
-//     weight image into registers (no LDS for B) and a three-stage LDS ring for A reached 1.15 us per K-tile with A in
-//     the Infinity Cache (MFMAs alone 0.75, + LDS fragment reads and loads 1.06, + split and LDS stores 1.15) but
-//     1.8-1.9 us from HBM (the wait for the A loads shows again: four K-tiles of lead are not enough there) and paid
-//     ~20 us more per launch in prologue / epilogues that no second workgroup hides: 111 vs 113-122 us on post-layer 0
-//     (K = 640), 73 vs 69 us on the K = 384 product, 106-110 vs 84-86 us on K = 128 -> N = 512.  Pinning the order of
-//     MFMA groups, fragment reads and LDS stores with sched_barrier, and a 1 x 4 instead of a 2 x 2 wave grid (B read
-//     once per workgroup: L2 serves ~70 GB/s per CU, the Infinity Cache ~33, HBM ~24) did not move these numbers.
-//     Not faster on the shapes of the model, so not kept; what a faster kernel needs is a deeper A prefetch (LDS-DMA)
-//     AND an epilogue that overlaps the next tile, i.e. the structure of the weights-stationary kernel below.
+//     weight image into registers and a three-stage LDS ring for A reached 1.15 us per K-tile with A in the Infinity
+//     Cache (MFMAs alone 0.75, + fragment reads and loads 1.06, + split and LDS stores 1.15) but 1.8-1.9 us from HBM
+//     and ~20 us more per launch in prologue / epilogues that no second workgroup hides: not faster (111 vs 113-122 us
+//     on post-layer 0).  Pinning the order of MFMA groups, fragment reads and LDS stores with sched_barrier and a
+//     1 x 4 instead of a 2 x 2 wave grid (B read once per workgroup: L2 serves ~70 GB/s per CU, the Infinity Cache
+//     ~33, HBM ~24) did not move these numbers;
+//   * the same pipeline with TWO workgroups per CU (two-stage ring, no cross-barrier fragment prefetch, 218 VGPRs) is
+//     k_gemm3p below: 0.9 us per K-tile and CU once both workgroups are in their K loops (the MFMA floor), 1.1 / 1.4 us
+//     per K-tile over whole launches (Infinity Cache / HBM) against 1.75 / 2.0 us here.  It takes the products with
+//     >= 12 K-tiles per tile; this kernel keeps the shorter ones (equal speed at 4 and 8 K-tiles, shorter prologue).
 template <int EPI>
 __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   __shared__ __attribute__((aligned(16))) unsigned char A3[G3_OP];
@@ -1061,6 +1075,324 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined form of k_gemm3 (same contract, same arithmetic, same tile walk, two workgroups per CU).
+//   * B never touches LDS: k_split_weights writes the images FRAGMENT-major, so a lane fetches its 16-byte MFMA operand
+//     straight from L2 (a wave reads 1 KB contiguous per fragment); wave w multiplies all 128 rows by the 32 columns
+//     32 w .., so the four waves read disjoint fragments (24 KB per K-tile and workgroup) and a slab's registers are
+//     refilled with the next K-tile's fragments right after its MFMAs are issued;
+//   * A: global loads three K-tiles ahead (two register stages), split + ds_write ONE K-tile ahead into the other half
+//     of a two-stage LDS ring, inside the MFMA block of the current K-tile; ONE barrier per K-tile;
+//   * every load of the loop is unconditional (clamped addresses, validity applied at LDS-store time): a load inside a
+//     conditional block makes the compiler's s_waitcnt insertion fall back to vmcnt(0), i.e. exposes the memory latency;
+//   * the second workgroup of the CU covers what one workgroup cannot hide: the LDS round trip behind the barrier,
+//     prologue, epilogue and tile switch.
+// Needs >= 4 K-tiles per output tile (the load cursor is at most one tile ahead of the multiply); used from 12.
+// Bit-identical to k_gemm3 (same MFMAs, same operands, same order per accumulator: tests/test_gemm_split_gpu.py).
+// Measured (tools/gemm3_diag.py, same box, us per launch, k_gemm3 -> k_gemm3p): post-layer 0 (K = 640) at 81 920 rows
+// 104 -> 97, at 131 072 rows 167 -> 151, at 655 360 rows 744 -> 643 (0.40 of the bf16 peak); K = 384 product 71.5 -> 62.7;
+// a lone workgroup's K-tile 1.36 us, two per CU 1.8 us each.  What is left is per-launch: ~25 us per workgroup of
+// prologue + epilogue (the two workgroups of a CU start and finish together, so these do not overlap) and cfg-2's 640
+// tiles on 512 workgroups; whole step (tools/ab_bench.py base / nopipe): cfg-2 7.75 vs 7.82 ms, cfg-4's batch 27.2 vs 27.5.
+// ---------------------------------------------------------------------------------------------------------------
+#define G3P_STAGES 2
+#define G3P_MIN_KTILES 12  // shorter K: the two-barrier kernel is as fast (measured at 4 and 8 K-tiles) and has the shorter prologue
+#define G3P_LDS (G3P_STAGES * G3_OP + 2 * BM * 4)
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_p[];
+  unsigned char* const Abuf = lds_p;                                     // [2][G3_OP]
+  int* const rid = reinterpret_cast<int*>(lds_p + G3P_STAGES * G3_OP);   // [2][BM]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  // wave w multiplies ALL 128 rows by the 32 columns w*32..: the four waves read disjoint B fragments (24 KB per
+  // K-tile and workgroup from L2; a 2 x 2 wave grid reads every fragment twice, and at ~70 GB/s per CU from L2 plus
+  // ~30 GB/s per CU for A that, not the matrix pipe, bounds the K-tile)
+  const int li = lane & 31, lh = lane >> 5;
+  const int lrow = tid >> 3, lk4 = (tid & 7) * 4;
+  const int NT = g.Npad / BN, KT = g.Kpad / BK;
+
+  const int ny = g.ny, G = gridDim.x;
+  const bool grouped = g.tile_info != nullptr;
+  const int nrt = grouped ? g.ntiles[0] : (int)((g.M + BM - 1) / BM);
+  auto row_tile_of = [&](int v) { return (v / (8 * ny)) * 8 + ((v % (8 * ny)) & 7); };
+  auto n0_of = [&](int v) { return ((v % (8 * ny)) >> 3) * BN; };
+
+  int v_l = blockIdx.x;  // tile of the A load cursor (the multiply is at most one tile behind it)
+  if (row_tile_of(v_l) >= nrt) return;
+
+  auto fetch_ti = [&](int v, int& p0, int& pr, int& c) {
+    const int rt = row_tile_of(v);
+    const int rtc = rt < nrt ? rt : 0;
+    p0 = g.tile_info[3 * rtc];
+    pr = g.tile_info[3 * rtc + 1];
+    c = g.tile_info[3 * rtc + 2];
+  };
+  // row ids of a tile: RAW loaded values; the r < rows select is applied where the ids are consumed, a tile later (a
+  // select right here would wait for these loads, and with them for every K-tile load in flight, at each tile switch)
+  auto fetch_rows = [&](int v, int p0, int pr, int c, int (&gr)[4], int& rt_id, int& cl) {
+    const int t = tid < BM ? tid : 0;
+    if (grouped) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = lrow + 32 * q;
+        gr[q] = g.row_index[p0 + (r < pr ? r : 0)];
+      }
+      rt_id = g.row_index[p0 + (t < pr ? t : 0)];
+      cl = c;
+    } else {
+      const int64_t m0 = (int64_t)row_tile_of(v) * BM;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gr[q] = (int)(m0 + lrow + 32 * q);
+      rt_id = (int)(m0 + t);
+      cl = 0;
+    }
+  };
+  auto rows_in_tile = [&](int v, int pr) {
+    return grouped ? pr : (int)min((int64_t)BM, g.M - (int64_t)row_tile_of(v) * BM);
+  };
+
+  // A cursor's tile (cgrow), the tile after it (grow_n ..: row ids fetched one tile ahead, its tile_info two ahead), and
+  // what the multiply / the B cursor take over when they reach the tile the A cursor has entered (ridt_p, n0_p, cls_p)
+  int cgrow[4], grow_n[4] = {0, 0, 0, 0}, ridt_n = 0, pr_n = 0, cls_n = 0, n0_n = 0, ti2_p0 = 0, ti2_pr = 0, ti2_cls = 0;
+  int n0_c, ridt_p = -1, n0_p = 0, cls_p = 0;
+  bool valid_n, pend = false, cursor_valid = true;
+  int tpar = 0, cls0 = 0;
+  {
+    int p0 = 0, pr = 0, c = 0, rt_id, cl;
+    if (grouped) fetch_ti(v_l, p0, pr, c);
+    fetch_rows(v_l, p0, pr, c, cgrow, rt_id, cl);
+    {
+      const int nr = rows_in_tile(v_l, pr);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cgrow[q] = (lrow + 32 * q < nr) ? cgrow[q] : -1;
+      if (tid < BM) rid[tid] = tid < nr ? rt_id : -1;
+    }
+    n0_c = n0_of(v_l);
+    valid_n = row_tile_of(v_l + G) < nrt;
+    if (valid_n) {
+      if (grouped) fetch_ti(v_l + G, p0, pr, c);
+      fetch_rows(v_l + G, p0, pr, c, grow_n, ridt_n, cls_n);
+      pr_n = rows_in_tile(v_l + G, pr);
+      n0_n = n0_of(v_l + G);
+    }
+    if (grouped) fetch_ti(v_l + 2 * G, ti2_p0, ti2_pr, ti2_cls);
+    cls0 = cl;
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  f32x4 ra[2][4];          // A K-tiles in flight (fp32), two register stages
+  int kvalid[2] = {0, 0};
+  bf16x8 bfr[2][3];        // B fragments [slab][piece]: a slab is refilled (next K-tile) right after its MFMAs
+
+  // ---- A cursor
+  const float* rowp[4];
+  int rowv = 0, segK = 0, s1 = 0, k1 = 0;
+  auto enter_segment = [&](int s_i) {
+    const seg_dev& s = g.seg[s_i];
+    rowv = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      rowp[q] = s.a + (int64_t)(cgrow[q] >= 0 ? cgrow[q] : 0) * s.lda;
+      rowv |= cgrow[q] >= 0 ? (1 << q) : 0;
+    }
+    segK = s.k;
+  };
+  auto load_a = [&](auto PC) {  // K-tile at the cursor -> register stage P (always issued)
+    constexpr int P = decltype(PC)::value;
+    const int k = k1 + lk4;
+    const bool k_ok = k < segK;
+    const int kc = k_ok ? k : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[P][q] = *reinterpret_cast<const f32x4*>(rowp[q] + kc);
+    kvalid[P] = (k_ok && cursor_valid) ? rowv : 0;
+  };
+  auto cursor_step = [&]() {
+    if (!cursor_valid) return;
+    k1 += BK;
+    if (k1 < segK) return;
+    ++s1;
+    k1 = 0;
+    if (s1 < g.nseg) {
+      enter_segment(s1);
+      return;
+    }
+    s1 = 0;
+    if (valid_n) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cgrow[q] = (lrow + 32 * q < pr_n) ? grow_n[q] : -1;
+      enter_segment(0);
+      ridt_p = tid < pr_n ? ridt_n : -1;
+      n0_p = n0_n;
+      cls_p = cls_n;
+      pend = true;
+      v_l += G;
+      valid_n = row_tile_of(v_l + G) < nrt;
+      if (valid_n) {
+        fetch_rows(v_l + G, ti2_p0, ti2_pr, ti2_cls, grow_n, ridt_n, cls_n);
+        pr_n = rows_in_tile(v_l + G, ti2_pr);
+        n0_n = n0_of(v_l + G);
+      }
+      if (grouped) fetch_ti(v_l + 2 * G, ti2_p0, ti2_pr, ti2_cls);
+    } else {
+      cursor_valid = false;  // the loads go on over the last tile's first K-tile and are never multiplied
+      enter_segment(0);
+    }
+  };
+
+  // ---- B cursor: this lane's 16-byte slot of the fragment-major block [slab][piece][ni 0..3][lane][8] of a K-tile
+  const __bf16* bptr;
+  int kb = 0;
+  bool b_valid = true;
+  auto b_tile_base = [&](int cl, int nn0) {
+    return g.bsplit + (((int64_t)cl * NT + nn0 / BN) * KT * 3) * (BN * BK) + (wave * 64 + lane) * 8;
+  };
+  auto load_b = [&](int sl) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bfr[sl][p] = *reinterpret_cast<const bf16x8*>(bptr + ((sl * 3 + p) * 4 * 64) * 8);
+  };
+  auto b_step = [&]() {
+    if (!b_valid) return;
+    bptr += 3 * (BN * BK);
+    if (++kb < KT) return;
+    kb = 0;
+    if (pend) {
+      bptr = b_tile_base(cls_p, n0_p);
+    } else {
+      b_valid = false;
+      bptr = b_tile_base(0, 0);
+    }
+  };
+
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  auto store_a = [&](auto PC, unsigned char* A3) {  // register stage P -> LDS stage at A3
+    constexpr int P = decltype(PC)::value;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float xa[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[4 * q + j] = ((kvalid[P] >> (2 * h + q)) & 1) ? ra[P][2 * h + q][j] : 0.f;
+      bf16x8 pc[3];
+      split3(xa, pc[0], pc[1], pc[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+        unsigned char* qa = A3 + p * G3_PIECE + (lrow + 64 * h) * G3_LDB + lk4 * 2;
+        *reinterpret_cast<f32x2*>(qa) = f32x2{w.x, w.y};
+        *reinterpret_cast<f32x2*>(qa + 32 * G3_LDB) = f32x2{w.z, w.w};
+      }
+    }
+  };
+  const int afrag = li * G3_LDB + 16 * lh;  // this lane's fragment offset inside an image (mi = 0, slab 0)
+  auto read_a1 = [&](const unsigned char* A3, int sl, int mi, bf16x8 (&a)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      a[p] = *reinterpret_cast<const bf16x8*>(A3 + p * G3_PIECE + afrag + mi * 32 * G3_LDB + 32 * sl);
+  };
+  auto read_a = [&](const unsigned char* A3, int sl, bf16x8 (&a)[4][3]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) read_a1(A3, sl, mi, a[mi]);
+  };
+  auto mfma_group = [&](f32x16& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  };
+
+  float bv;
+  auto fetch_bias = [&](int nn0) {
+    const int gc = nn0 + wave * 32 + li;
+    bv = (g.bias != nullptr && gc < g.N) ? g.bias[gc] : 0.f;
+  };
+  fetch_bias(n0_c);
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: A K-tile 0 in LDS stage 0; K-tiles 1, 2 in flight (register stages 1, 0); B K-tile 0 in flight
+  enter_segment(0);
+  bptr = b_tile_base(cls0, n0_c);
+  load_a(I0{});
+  cursor_step();
+  load_a(I1{});
+  cursor_step();
+  load_b(0);
+  load_b(1);
+  b_step();
+  store_a(I0{}, Abuf);
+  load_a(I0{});
+  cursor_step();
+  __syncthreads();
+
+  int kc = 0;
+  bool done = false;
+  auto iteration = [&](auto SC, auto PC) {  // S = j & 1: LDS stage of K-tile j; P = 1 - S: register stage of K-tile j + 1
+    const unsigned char* const Ac = Abuf + decltype(SC)::value * G3_OP;
+    unsigned char* const As = Abuf + decltype(PC)::value * G3_OP;
+    // multiply K-tile j || split K-tile j + 1 into the other LDS stage || refill each slab's B fragments (K-tile j + 1)
+    bf16x8 af[4][3];
+    read_a(Ac, 0, af);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      mfma_group(acc[mi], af[mi], bfr[0]);
+      read_a1(Ac, 1, mi, af[mi]);
+    }
+    load_b(0);
+    store_a(PC, As);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) mfma_group(acc[mi], af[mi], bfr[1]);
+    load_b(1);
+    b_step();
+    load_a(PC);  // A K-tile j + 3 (register stage P was stored just above)
+    if (++kc == KT) {  // tile finished
+      const int* rt = rid + tpar * BM;
+      const int gc = n0_c + wave * 32 + li;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        int rows[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rows[r] = rt[mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        epilogue_tile<EPI>(acc[mi], rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+      }
+      if (!pend) {
+        done = true;
+        return;
+      }
+      // take over the tile the A cursor entered three K-tiles ago (other rid stage: its last readers were the epilogue
+      // of the tile before this one)
+      tpar ^= 1;
+      if (tid < BM) rid[tpar * BM + tid] = ridt_p;
+      n0_c = n0_p;
+      fetch_bias(n0_c);
+      pend = false;
+      kc = 0;
+    }
+    cursor_step();
+    __syncthreads();
+  };
+  while (true) {
+    iteration(I0{}, I1{});
+    if (done) break;
+    iteration(I1{}, I0{});
+    if (done) break;
+  }
+}
+
 template <bool BT, int EPI>
 static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
   static bool attr_set = false;
@@ -1290,6 +1622,7 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     if (g3 > slots) g3 = slots;
   }
   const dim3 grid3(g3);
+  bool pipe = h->opt[GNX_OPT_GEMM_PIPE] != 0;  // decided below: needs >= G3P_MIN_KTILES K-tiles per output tile
   bool vec = h->opt[GNX_OPT_GEMM_VEC] != 0;
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
@@ -1322,6 +1655,8 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     sa.Npad = (int)gnx_cdiv((int64_t)N, BN) * BN;
     sa.Kpad = kp;
     sa.D = num_classes > 0 ? num_classes : 1;
+    pipe = pipe && kp / BK >= G3P_MIN_KTILES;
+    sa.frag = pipe ? 1 : 0;
     sa.out = reinterpret_cast<__bf16*>(ws);
     const int64_t items = (int64_t)sa.D * sa.Npad * (sa.Kpad / 8);
     if (bt)
@@ -1337,7 +1672,10 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
     if (split) {                                                                          \
-      hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);              \
+      if (pipe)                                                                           \
+        hipLaunchKernelGGL((k_gemm3p<EPI>), grid3, dim3(256), G3P_LDS, h->stream, g);     \
+      else                                                                                \
+        hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);            \
     } else if (vec)                                                                       \
       hipLaunchKernelGGL((k_gemm<BT, EPI, true>), grid, dim3(256), 0, h->stream, g);      \
     else                                                                                  \

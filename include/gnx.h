@@ -59,7 +59,8 @@ enum {
   GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
   GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 4096 */
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
-  GNX_OPT_COUNT = 8
+  GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
+  GNX_OPT_COUNT = 9
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);

@@ -102,6 +102,89 @@ def test_grouped_by_degree_class(gpu_device):
     assert rel_err(dA, ref_dA) <= TOL
 
 
+def _both_tiled_kernels(fn):
+    """fn() through the software-pipelined kernel (default for >= 12 K-tiles) and through the two-barrier kernel."""
+    from gnnepcsaft_amd import ops
+    outs = []
+    for pipe in (1, 0):
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_PIPE, pipe)
+        try:
+            outs.append(fn())
+        finally:
+            ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_PIPE, 1)
+    return outs
+
+
+def test_pipelined_and_two_barrier_tiled_kernels_are_bit_identical(gpu_device):
+    """k_gemm3p and k_gemm3 issue the same MFMAs on the same operands in the same order per accumulator (only the
+    staging differs: B fragments straight from a fragment-major image, one barrier per K-tile): bit-identical outputs
+    for every epilogue, ragged shapes, several column tiles, strided views and degree-class grouping -- and both within
+    1e-5 of fp64."""
+    from gnnepcsaft_amd import ops
+    torch.manual_seed(21)
+    F = 128
+    # (a) post-layer-0 shape, two segments, bias + ReLU; ragged M
+    M = 20037
+    x, A = torch.randn(M, F), torch.randn(M, 4 * F)
+    W, b = torch.randn(F, 5 * F) / 8, torch.randn(F)
+    xd, Ad, Wd, bd = x.to(gpu_device), A.to(gpu_device), W.to(gpu_device), b.to(gpu_device)
+
+    def post0():
+        out = torch.full((M, F), float("nan"), device=gpu_device)
+        ops.gemm([(xd, None, Wd[:, :F]), (Ad, None, Wd[:, F:])], out, bias=bd, relu=True)
+        return out
+    p, q = _both_tiled_kernels(post0)
+    assert torch.equal(p, q)
+    assert rel_err(p, (torch.cat([x, A], 1).double() @ W.double().T + b.double()).relu()) <= TOL
+    # (b) three NN segments with k not a multiple of 32 (4 + 4 + 5 K-tiles), strided operand / output views, accumulate
+    M2 = 9001
+    big = torch.randn(M2, 3 * 160)
+    ks = (100, 128, 156)
+    ws = [torch.randn(k, 96) / 4 for k in ks]
+    c0 = torch.randn(M2, 200)
+    bigd, wsd = big.to(gpu_device), [w.to(gpu_device) for w in ws]
+
+    def three():
+        outw = c0.clone().to(gpu_device)
+        ops.gemm([(bigd[:, 160 * i:160 * i + k], None, wsd[i]) for i, k in enumerate(ks)], outw[:, 8:104], b_trans=False,
+                 accumulate=True)
+        return outw
+    p, q = _both_tiled_kernels(three)
+    assert torch.equal(p, q)
+    ref = c0.double().clone()
+    ref[:, 8:104] += sum(big[:, 160 * i:160 * i + k].double() @ ws[i].double() for i, k in enumerate(ks))
+    assert rel_err(p, ref) <= TOL
+    # (c) two column tiles, K = 400 (13 K-tiles), ReLU-mask epilogue
+    M3, N3, K3 = 33000, 256, 400
+    a, w, mask = torch.randn(M3, K3), torch.randn(K3, N3) / 4, torch.randn(M3, N3)
+    ad, wd, md = a.to(gpu_device), w.to(gpu_device), mask.to(gpu_device)
+
+    def wide():
+        out = torch.full((M3, N3), float("nan"), device=gpu_device)
+        ops.gemm([(ad, None, wd)], out, b_trans=False, mask=md)
+        return out
+    p, q = _both_tiled_kernels(wide)
+    assert torch.equal(p, q)
+    assert rel_err(p, (a.double() @ w.double()) * (mask > 0)) <= TOL
+    # (d) rows gathered by in-degree class with per-class weights (K = 128 + 512)
+    rng = np.random.default_rng(5)
+    N, E = 30000, 70000
+    g = _pack(_graph(rng, N, E), None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    assert dc is not None
+    xg, Ag = torch.randn(N, F, device=gpu_device), torch.randn(N, 4 * F, device=gpu_device)
+    Wp = torch.randn(F, 13 * F, device=gpu_device) / 8
+    weff = ops.pna_weff(Wp, F, dc.D, 1.2)
+
+    def grouped():
+        z = torch.full((N, F), float("nan"), device=gpu_device)
+        ops.gemm_grouped([(xg, None, Wp[:, 0:F], 0), (Ag, None, weff[0], 4 * F * F)], z, dc, bias=bd, relu=True)
+        return z
+    p, q = _both_tiled_kernels(grouped)
+    assert torch.equal(p, q)
+    assert not torch.isnan(p).any()
+
+
 def test_split_and_exact_kernels_agree(gpu_device):
     """Same call through the split-operand kernel and the exact-fp32 MFMA kernel: both within 1e-5 of fp64 and within
     2e-6 (norm-wise) of each other."""

@@ -16,7 +16,8 @@ cases = {
 }
 for name, (fn, byts, flops) in cases.items():
     for mode in (os.environ.get("DIAG_MODES", "1,0").split(",")):
-        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, 1 if int(mode) else 0)
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_PIPE, 1 if int(mode) == 2 else 0)
         for _ in range(5): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,6 +9,7 @@ M, F = int(os.environ.get("DIAG_M", "65536")), 128
 for mode in os.environ.get("DIAG_MODES", "1,0").split(","):
     mode = int(mode)
     ops.set_option(dev, _lib.OPT_GEMM_SPLIT, 1 if mode else 0)
+    ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1 if mode == 2 else 0)
     res = []
     for K in (256, 512, 1024):
         A = torch.randn(M, K, device=dev); W = torch.randn(F, K, device=dev); z = torch.empty(M, F, device=dev)
