@@ -1091,9 +1091,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
 // Bit-identical to k_gemm3 (same MFMAs, same operands, same order per accumulator: tests/test_gemm_split_gpu.py).
 // Measured (tools/gemm3_diag.py, same box, us per launch, k_gemm3 -> k_gemm3p): post-layer 0 (K = 640) at 81 920 rows
 // 104 -> 97, at 131 072 rows 167 -> 151, at 655 360 rows 744 -> 643 (0.40 of the bf16 peak); K = 384 product 71.5 -> 62.7;
-// a lone workgroup's K-tile 1.36 us, two per CU 1.8 us each.  What is left is per-launch: ~25 us per workgroup of
-// prologue + epilogue (the two workgroups of a CU start and finish together, so these do not overlap) and cfg-2's 640
-// tiles on 512 workgroups; whole step (tools/ab_bench.py base / nopipe): cfg-2 7.75 vs 7.82 ms, cfg-4's batch 27.2 vs 27.5.
+// a lone workgroup's K-tile 1.36 us.  In-kernel wall-clock stamps (65 536 rows, one tile per workgroup, K = 640): prologue
+// 3.4-5.1 us, K loop 2.0 us per K-tile in the CU's first workgroup and 2.4 us in its second (= 1.1-1.2 us per K-tile and CU
+// against the 0.87 us MFMA floor), epilogue (64 four-byte stores per lane) 3.0-5.0 us, workgroup lifetime 48-57 us inside a
+// 65 us kernel (dispatch of 2048 waves and the final write-back are the rest); on top of that cfg-2's 640 tiles meet 512
+// workgroups; whole step (tools/ab_bench.py base / nopipe): cfg-2 7.75 vs 7.82 ms, cfg-4's batch 27.2 vs 27.5.
 // ---------------------------------------------------------------------------------------------------------------
 #define G3P_STAGES 2
 #define G3P_MIN_KTILES 12  // shorter K: the two-barrier kernel is as fast (measured at 4 and 8 K-tiles) and has the shorter prologue
