@@ -31,6 +31,8 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
   hipError_t e = hipMalloc(&h->d_flag, 256);
   if (e == hipSuccess) e = hipMalloc(&h->d_scratch, 4096);
   if (e == hipSuccess) e = hipMemset(h->d_flag, 0, 256);
+  if (e == hipSuccess) e = hipMalloc(&h->d_zero, 256);
+  if (e == hipSuccess) e = hipMemset(h->d_zero, 0, 256);
   if (e != hipSuccess) {
     gnx_set_error("gnx_create: %s", hipGetErrorString(e));
     delete h;
@@ -45,7 +47,8 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
               {GNX_OPT_GEMM_VEC, "GNX_GEMM_VEC", 1},           {GNX_OPT_WGRAD_VEC, "GNX_WGRAD_VEC", 1},
               {GNX_OPT_WGRAD_WGS, "GNX_WGRAD_WGS", 0},         {GNX_OPT_AGG_BWD_RECOMPUTE, "GNX_AGG_BWD_RECOMPUTE", 1},
               {GNX_OPT_EMBED_BWD_MFMA, "GNX_EMBED_BWD_MFMA", 1}, {GNX_OPT_STD_BWD_CENTERED, "GNX_STD_BWD_CENTERED", 1},
-              {GNX_OPT_GEMM_PIPE, "GNX_GEMM_PIPE", 1}};
+              {GNX_OPT_GEMM_PIPE, "GNX_GEMM_PIPE", 1},
+              {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1}};
   for (const auto& o : opts) {
     const char* e = getenv(o.env);
     h->opt[o.id] = e ? atoi(e) : o.def;
@@ -71,6 +74,7 @@ extern "C" int32_t gnx_destroy(gnx_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   (void)hipFree(h->d_flag);
   (void)hipFree(h->d_scratch);
+  (void)hipFree(h->d_zero);
   for (int i = 0; i < gnx_handle::kSideStreams; ++i) {
     if (h->side_fork[i]) (void)hipEventDestroy(h->side_fork[i]);
     if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);

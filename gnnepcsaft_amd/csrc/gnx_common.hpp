@@ -16,6 +16,7 @@ struct gnx_handle {
   // sticky device-side range flag + small scratch (handle state, not tensor memory)
   int* d_flag = nullptr;
   float* d_scratch = nullptr;  // 4 KiB
+  float* d_zero = nullptr;     // 256 zero bytes, never written: what a masked-out vector load reads
   // side streams (gnx_side_begin/end/join): created on first use; `stream` is swapped to one between begin and end
   static constexpr int kSideStreams = 2;
   hipStream_t side[kSideStreams] = {nullptr, nullptr};

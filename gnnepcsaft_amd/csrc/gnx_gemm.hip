@@ -1749,6 +1749,7 @@ struct wgrad_args {
   const int* chunk_info;
   const int* nchunks;
   int64_t dw_cls_stride;
+  const float* zero;  // 16 readable zero bytes (k_gemm_wgrad3p: target of masked-out loads)
 };
 
 template <bool VEC, bool GROUPED>
@@ -2099,6 +2100,227 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
   wgrad3_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, A3, B3, offs);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised split-operand weight gradient (same contract and arithmetic as wgrad3_body for 16-byte aligned
+// operands with N, K multiples of 4), ONE 512-thread workgroup per CU -- the weight-gradient launches are sized to one
+// workgroup per CU anyway, and in the two-barrier body above such a lone workgroup runs its phases back to back: 32
+// four-byte loads per thread, wait, split, LDS stores, barrier, fragment reads, 48 MFMAs, barrier = 2.5-2.8 us per
+// 32-row step against 0.65-0.87 us of MFMA time (SQ_VALU_MFMA_BUSY_CYCLES: 0.20-0.26 of the matrix pipe; ablations:
+// split + LDS stores alone 1.0 us, fragment reads + MFMAs alone 1.27 us, and the compiler keeps the two apart even
+// inside one basic block).  Here the phases belong to different waves of the same SIMD, which the hardware overlaps:
+//   * waves 0..3 multiply: fragment reads + 48 MFMAs per step out of the LDS stage of step j (2 x 2 tiles of 64 x 64);
+//   * waves 4..7 stage: threads 256..383 dC, 384..511 A -- eight 16-byte loads each (8 rows x 4 columns) issued five
+//     steps ahead into four register stages (128 KB in flight per CU), always unconditional (invalid rows / columns read a zero line instead of
+//     being masked), split column by column and written as 16-byte LDS words into the [column][32 m] bf16 images of
+//     step j + 1 (two-stage ring, 120 KB); they also accumulate the bias gradient;
+//   * ONE barrier per step joins the two groups;
+//   * GROUPED: the element offsets of a step's 32 gathered rows are staged in LDS by every staging wave redundantly
+//     (no divergent block around a load), from an index load issued one step before it is consumed.
+// ---------------------------------------------------------------------------------------------------------------
+#define WG3P_LDS (4 * G3_OP + 2 * 64 * 4)
+#define WG3P_NST 4  // register stages of the staging waves (must be 4: the prologue and the unrolled loop assume it)
+
+template <bool GROUPED>
+__device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, const int by, const int bz,
+                                             unsigned char* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n0 = by * BN;  // dW row tile (output features)
+  const int c0 = bz * BN;  // dW col tile (input features)
+  if (n0 >= g.N || c0 >= g.K) return;
+  int64_t r_begin = (int64_t)bx * g.rows_per_block;
+  int64_t r_end = r_begin + g.rows_per_block;
+  if (r_end > g.M) r_end = g.M;
+  float* dW = g.dW;
+  if constexpr (GROUPED) {
+    if (bx >= g.nchunks[0]) return;
+    r_begin = g.chunk_info[3 * bx];
+    r_end = r_begin + g.chunk_info[3 * bx + 1];
+    dW += (int64_t)g.chunk_info[3 * bx + 2] * g.dw_cls_stride;
+  }
+  if (r_begin >= r_end) return;
+  const int64_t nsteps = (r_end - r_begin + BK - 1) / BK;
+  // barriers of the prologue (both groups execute the same number): GROUPED stages two pairs of offset buffers first
+  constexpr int PROLOGUE_BARRIERS = GROUPED ? 7 : 1;
+
+  if (wave < 4) {
+    // ================================================================ multiply waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < PROLOGUE_BARRIERS; ++b) __syncthreads();
+    for (int64_t j = 0; j < nsteps; ++j) {
+      const unsigned char* const A3 = lds + (j & 1) * 2 * G3_OP;
+      const unsigned char* const B3 = A3 + G3_OP;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            a[mi][p] = *reinterpret_cast<const bf16x8*>(A3 + p * G3_PIECE + (wm * 64 + mi * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            b[ni][p] = *reinterpret_cast<const bf16x8*>(B3 + p * G3_PIECE + (wn * 64 + ni * 32 + li) * G3_LDB + 32 * sl + 16 * lh);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        int gc = c0 + wn * 64 + ni * 32 + li;
+        if (gc >= g.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int gr = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (gr >= g.N) continue;
+          atomicAdd(dW + (int64_t)gr * g.lddw + gc, acc[mi][ni][r]);
+        }
+      }
+    return;
+  }
+
+  // ================================================================== staging waves
+  unsigned* const offs = reinterpret_cast<unsigned*>(lds + 4 * G3_OP);  // [2][X | Y][32]
+  const int lt = tid - 256;
+  const int role = lt >> 7;  // 0: dC (dW rows n0..), 1: A (dW columns c0..)
+  const int c4 = (lt & 31) * 4, rg = (lt >> 5) & 3;
+  const bool col_ok = role ? (c0 + c4 < g.K) : (n0 + c4 < g.N);  // N, K multiples of 4: the quad is valid as a whole
+  const float* const base = (role ? g.Y + (col_ok ? c0 + c4 : 0) : g.X + (col_ok ? n0 + c4 : 0));
+  const float* const zero = g.zero;  // 16 zero bytes: what an invalid row or column quad reads
+  const int64_t ld = role ? g.ldy : g.ldx;
+  const int img = role * G3_OP;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // role 0: column sums of dC (bias gradient)
+
+  f32x4 v[WG3P_NST][8];  // register stages: the loads of WG3P_NST steps in flight (32 KB per stage and workgroup)
+  unsigned ri = 0u;      // GROUPED: row index of row (lt & 31) of the step whose offsets are written next
+
+  auto index_of = [&](int64_t r0) -> unsigned {
+    const int t = lt & 31;
+    const int64_t pos = r0 + t < r_end ? r0 + t : r_begin;
+    return (unsigned)g.row_index[pos];
+  };
+  auto write_offsets = [&](unsigned row, int ob) {  // every staging wave writes the same 64 words
+    const int t = lt & 31;
+    offs[ob * 64 + t] = row * (unsigned)g.ldx;
+    offs[ob * 64 + 32 + t] = row * (unsigned)g.ldy;
+  };
+  auto load_step = [&](auto PC, int64_t r0, int ob) {
+    constexpr int P = decltype(PC)::value;
+    const int64_t left = r_end - (r0 + rg * 8);
+    const int nval = (left >= 8 && col_ok) ? 8 : ((left > 0 && col_ok) ? (int)left : 0);
+    if constexpr (GROUPED) {
+      const unsigned* o = offs + ob * 64 + role * 32 + rg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[P][j] = *reinterpret_cast<const f32x4*>(j < nval ? base + o[j] : zero);
+    } else {
+      const float* p = base + (r0 + rg * 8) * ld;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[P][j] = *reinterpret_cast<const f32x4*>(j < nval ? p + j * ld : zero);
+    }
+  };
+  auto store_step = [&](auto PC, unsigned char* stage) {
+    constexpr int P = decltype(PC)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float xa[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xa[j] = v[P][j][q];
+      if (role == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[q] += xa[j];
+      }
+      bf16x8 p1, p2, p3;
+      split3(xa, p1, p2, p3);
+      unsigned char* dst = stage + img + (c4 + q) * G3_LDB + rg * 16;
+      *reinterpret_cast<bf16x8*>(dst) = p1;
+      *reinterpret_cast<bf16x8*>(dst + G3_PIECE) = p2;
+      *reinterpret_cast<bf16x8*>(dst + 2 * G3_PIECE) = p3;
+    }
+  };
+  auto row_of = [&](int64_t step) { return r_begin + step * BK; };
+  auto IC = [](auto c) { return c; };
+  (void)IC;
+
+  // ---- prologue: steps 0 .. NST-1 loaded, step 0 split into LDS stage 0, step NST loaded into its register stage.
+  // GROUPED: the offsets are staged two steps at a time (two buffers) in front of the loads that read them; at the end
+  // the offsets of step NST + 1 are in place and the index of step NST + 2 is in flight.
+  {
+    auto round = [&](auto A, auto B, int64_t sa, bool second) {
+      if constexpr (GROUPED) {
+        write_offsets(index_of(row_of(sa)), (int)(sa & 1));
+        write_offsets(index_of(row_of(sa + 1)), (int)((sa + 1) & 1));
+        __syncthreads();
+      }
+      load_step(A, row_of(sa), (int)(sa & 1));
+      if (second) load_step(B, row_of(sa + 1), (int)((sa + 1) & 1));
+      if constexpr (GROUPED) __syncthreads();
+    };
+    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, true);
+    round(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, 2, true);
+    store_step(std::integral_constant<int, 0>{}, lds);
+    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 4, false);
+    if constexpr (GROUPED) ri = index_of(row_of(WG3P_NST + 2));
+    __syncthreads();
+  }
+
+  // iteration j (K = j % NST): split register stage (K + 1) % NST = step j + 1 into LDS stage (j + 1) & 1, then refill
+  // that register stage with step j + 1 + NST
+  auto iteration = [&](auto KC, int64_t j) {
+    constexpr int K = decltype(KC)::value;
+    constexpr int P = (K + 1) % WG3P_NST;
+    if constexpr (GROUPED) {
+      write_offsets(ri, K & 1);                     // offsets of step j + 2 + NST (buffer parity = j & 1)
+      ri = index_of(row_of(j + 3 + WG3P_NST));      // consumed at the start of the next iteration
+    }
+    store_step(std::integral_constant<int, P>{}, lds + ((K + 1) & 1) * 2 * G3_OP);
+    load_step(std::integral_constant<int, P>{}, row_of(j + 1 + WG3P_NST), (K + 1) & 1);
+    __syncthreads();
+  };
+  for (int64_t j = 0; j < nsteps; j += 4) {
+    iteration(std::integral_constant<int, 0>{}, j);
+    if (j + 1 >= nsteps) break;
+    iteration(std::integral_constant<int, 1>{}, j + 1);
+    if (j + 2 >= nsteps) break;
+    iteration(std::integral_constant<int, 2>{}, j + 2);
+    if (j + 3 >= nsteps) break;
+    iteration(std::integral_constant<int, 3>{}, j + 3);
+  }
+  if (g.dbias != nullptr && bz == 0 && role == 0 && col_ok) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(g.dbias + n0 + c4 + q, bsum[q]);
+  }
+}
+
+template <bool GROUPED>
+__global__ void __launch_bounds__(512, 1) k_gemm_wgrad3p(wgrad_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
+  wgrad3p_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_w);
+}
+
 // Several independent weight gradients in ONE launch (a layer's same-shaped dW = g^T a products): blockIdx.x =
 // problem * chunks + chunk.  With P problems sharing the grid every workgroup owns a P x longer row range, so the
 // per-problem atomic flush shrinks P x at equal parallelism (a lone 128x128 dW over 82k rows flushes 33 MB of fp32
@@ -2161,6 +2383,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3_batched(wgrad_batch_args
   wgrad3_body<false>(g, chunk, by, bz, A3, B3, nullptr);
 }
 
+__global__ void __launch_bounds__(512, 1) k_gemm_wgrad3p_batched(wgrad_batch_args b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_wb[];
+  int prob, chunk, by, bz;
+  wgrad_batch_locate(b, blockIdx.x, prob, chunk, by, bz);
+  wgrad_args g = b.p[0];
+#pragma unroll
+  for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
+    if (i == prob) g = b.p[i];
+  wgrad3p_body<false>(g, chunk, by, bz, lds_wb);
+}
+
+template <typename KERNEL>
+static hipError_t wgrad3p_attr(KERNEL kern) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG3P_LDS);
+}
+
 // the split-operand weight-gradient kernels take over for large row counts (GNX_GEMM_SPLIT=0: fp32 MFMA everywhere)
 static bool wgrad_split_enabled(const gnx_handle* h, int64_t M, bool any_rowscale) {
   if (any_rowscale || M < 4096) return false;
@@ -2202,6 +2440,7 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   g.chunk_info = chunk_info;
   g.nchunks = nchunks;
   g.dw_cls_stride = dw_cls_stride;
+  g.zero = h->d_zero;
   dim3 grid((unsigned)(chunk_info ? max_chunks : gnx_cdiv(M, rows)), (unsigned)gnx_cdiv(N, BN), (unsigned)gnx_cdiv(K, BN));
   bool vec = g.vec_x && g.vec_y && (N % 4 == 0) && (K % 4 == 0);
   if (h->opt[GNX_OPT_WGRAD_VEC] == 0) vec = false;
@@ -2209,7 +2448,18 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   const bool wsplit = wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32);
   const double wfl = 2.0 * (double)M * N * K;
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD, 4.0 * M * ((double)N + K) + 4.0 * N * K, wfl, wsplit ? 6.0 * wfl : 0.0);
-  if (wsplit) {
+  if (wsplit && vec && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p<true>));
+      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p<false>));
+      attr_set = true;
+    }
+    if (chunk_info)
+      hipLaunchKernelGGL((k_gemm_wgrad3p<true>), grid, dim3(512), WG3P_LDS, h->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm_wgrad3p<false>), grid, dim3(512), WG3P_LDS, h->stream, g);
+  } else if (wsplit) {
     if (chunk_info)
       hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
     else
@@ -2336,6 +2586,7 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
     g.nchunks = nullptr;
     g.dw_cls_stride = 0;
     g.rows_per_block = 0;
+    g.zero = h->d_zero;
     b.p[i] = g;
     if (q.M > maxM) maxM = q.M;
     if (q.N > maxN) maxN = q.N;
@@ -2379,7 +2630,14 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
     wfl += 2.0 * (double)probs[i].M * probs[i].N * probs[i].K;
   }
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD_BATCHED, wby, wfl, wgrad_split_enabled(h, maxM, any_rs) ? 6.0 * wfl : 0.0);
-  if (wgrad_split_enabled(h, maxM, any_rs))
+  if (wgrad_split_enabled(h, maxM, any_rs) && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p_batched));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm_wgrad3p_batched, grid, dim3(512), WG3P_LDS, h->stream, b);
+  } else if (wgrad_split_enabled(h, maxM, any_rs))
     hipLaunchKernelGGL(k_gemm_wgrad3_batched, grid, dim3(256), 0, h->stream, b);
   else
     hipLaunchKernelGGL(k_gemm_wgrad_batched, grid, dim3(256), 0, h->stream, b);

@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(params=[1, 0], ids=["wave_specialised", "two_barrier"])
+def wgrad_kernel(request, gpu_device):
+    """Runs a weight-gradient test through k_gemm_wgrad3p (default) and through k_gemm_wgrad3 (GNX_OPT_WGRAD_PIPE = 0)."""
+    from gnnepcsaft_amd import ops
+    ops.set_option(torch.device("cuda:0"), _lib.OPT_WGRAD_PIPE, request.param)
+    yield request.param
+    ops.set_option(torch.device("cuda:0"), _lib.OPT_WGRAD_PIPE, 1)
+
+
 @pytest.mark.parametrize("M", [4096, 20037, 70000])
 def test_two_segments_nt_bias_relu(gpu_device, M):
     """post-layer-0 shape: [x | A] (K = 128 + 512) against W[:, :640], bias + ReLU."""
@@ -210,7 +219,7 @@ def test_split_and_exact_kernels_agree(gpu_device):
 
 
 @pytest.mark.parametrize("M,N,K", [(20001, 128, 128), (8192, 36, 100), (5000, 130, 260)])
-def test_split_weight_gradient_single(gpu_device, M, N, K):
+def test_split_weight_gradient_single(gpu_device, wgrad_kernel, M, N, K):
     """dW += dC^T A and db += column sums on the split-operand kernel (no row scale, M >= 4096): ragged shapes, strided
     views, accumulation into existing values."""
     from gnnepcsaft_amd import ops
@@ -225,7 +234,7 @@ def test_split_weight_gradient_single(gpu_device, M, N, K):
     assert rel_err(db, -1.0 + dc.double().sum(0)) <= TOL
 
 
-def test_split_weight_gradient_batched(gpu_device):
+def test_split_weight_gradient_batched(gpu_device, wgrad_kernel):
     """A layer's worth of independent weight gradients in one launch (different M, shared operands)."""
     from gnnepcsaft_amd import ops
     torch.manual_seed(12)
@@ -253,7 +262,7 @@ def test_split_weight_gradient_batched(gpu_device):
             assert float(dbs[i].abs().max()) == 0.0
 
 
-def test_split_weight_gradient_by_degree_class(gpu_device):
+def test_split_weight_gradient_by_degree_class(gpu_device, wgrad_kernel):
     """Post-layer-0 weight gradient through per-degree-class partial sums (gathered rows, K = 4F wide)."""
     from gnnepcsaft_amd import ops
     rng = np.random.default_rng(41)

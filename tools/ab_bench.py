@@ -18,6 +18,7 @@ VARIANTS = {
     "noside": lambda dev: ops.set_wgrad_side_stream(False),
     "nocentered": lambda dev: ops.set_option(dev, _lib.OPT_STD_BWD_CENTERED, 0),
     "nopipe": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_PIPE, 0),
+    "nowgpipe": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 0),
     "wgs1024": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 1024),
     "wgs96": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 96),
     "wgs128": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 128),
@@ -38,6 +39,7 @@ def reset(dev):
     Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True)
     ops.set_option(dev, _lib.OPT_STD_BWD_CENTERED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1)
+    ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
     ops.set_option(dev, _lib.OPT_WGRAD_WGS, 0); ops.DegreeClasses.WGRAD_ROWS = 1024; ops.set_wgrad_batching(True)
     for k, v in EXTRA_RESET.items():
         v(dev)

@@ -1,4 +1,5 @@
-"""A/B timing of the weight-gradient kernels: split-bf16 (default) vs fp32 MFMA (GNX_GEMM_SPLIT=0)."""
+"""A/B timing of the weight-gradient kernels: wave-specialised split kernel (default, mode 2), two-barrier split kernel
+(mode 1: GNX_OPT_WGRAD_PIPE = 0), fp32 MFMA (mode 0: GNX_OPT_GEMM_SPLIT = 0)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnepcsaft_amd import _lib, ops
@@ -12,8 +13,9 @@ for M, N, K, nprob in ((81920, 128, 128, 1), (81920, 128, 128, 8), (163840, 128,
         for i in range(nprob):
             ops.queue_wgrad(g[i], x[i], dw[i])
         ops.flush_wgrads()
-    for mode in ("1", "0"):
-        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, int(mode))
+    for mode in os.environ.get("DIAG_MODES", "2,1,0").split(","):
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, 1 if int(mode) else 0)
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_WGRAD_PIPE, 1 if int(mode) == 2 else 0)
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
