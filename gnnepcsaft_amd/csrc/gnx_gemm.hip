@@ -2116,6 +2116,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
 //   * ONE barrier per step joins the two groups;
 //   * GROUPED: the element offsets of a step's 32 gathered rows are staged in LDS by every staging wave redundantly
 //     (no divergent block around a load), from an index load issued one step before it is consumed.
+// Measured (tools/wgrad_ab.py, a layer's eight 81 920 x 128 x 128 problems in one launch = 671 MB): 235 -> 205 us (3.4 -> 3.9
+// TB/s); K = 512: 111 -> 94 us.  Ablations of this kernel: the loads alone 124 us (the HBM floor), + the multiply waves
+// 132 us, + the staging waves' split and stores instead 138 us, both 195-205 us: the two groups slow each other down.
+// tools/ubench/wave_specialised_overlap.hip isolates that: per step, multiply waves alone 0.91 us, staging waves alone
+// 0.60 us (split) / 0.84 us (+ the twelve ds_write_b128), both 1.04 us without and 1.41-1.46 us with the LDS stores --
+// the 16-byte LDS stores, not the split, are what the MFMA waves feel; 1.45 us is this structure's floor, the kernel
+// runs at 2.2 us (loads, masks, address arithmetic, bias sums on top).
 // ---------------------------------------------------------------------------------------------------------------
 #define WG3P_LDS (4 * G3_OP + 2 * 64 * 4)
 #define WG3P_NST 4  // register stages of the staging waves (must be 4: the prologue and the unrolled loop assume it)
