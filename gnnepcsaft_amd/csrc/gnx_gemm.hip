@@ -2113,9 +2113,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
 //     steps ahead into four register stages (128 KB in flight per CU), always unconditional (invalid rows / columns read a zero line instead of
 //     being masked), split column by column and written as 16-byte LDS words into the [column][32 m] bf16 images of
 //     step j + 1 (two-stage ring, 120 KB); they also accumulate the bias gradient;
-//   * ONE barrier per step joins the two groups;
-//   * GROUPED: the element offsets of a step's 32 gathered rows are staged in LDS by every staging wave redundantly
-//     (no divergent block around a load), from an index load issued one step before it is consumed.
+//   * ONE barrier per step joins the two groups.
+// Rows gathered by degree class stay on wgrad3_body: the same structure with LDS-staged row offsets was built, correct, and
+// SLOWER there (145 vs 123 us per launch: the per-class chunks are 1024 rows = 32 steps, too short for its prologue).
 // Measured (tools/wgrad_ab.py, a layer's eight 81 920 x 128 x 128 problems in one launch = 671 MB): 235 -> 205 us (3.4 -> 3.9
 // TB/s); K = 512: 111 -> 94 us.  Ablations of this kernel: the loads alone 124 us (the HBM floor), + the multiply waves
 // 132 us, + the staging waves' split and stores instead 138 us, both 195-205 us: the two groups slow each other down.
@@ -2124,10 +2124,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_wgrad3(wgrad_args g) {
 // the 16-byte LDS stores, not the split, are what the MFMA waves feel; 1.45 us is this structure's floor, the kernel
 // runs at 2.2 us (loads, masks, address arithmetic, bias sums on top).
 // ---------------------------------------------------------------------------------------------------------------
-#define WG3P_LDS (4 * G3_OP + 2 * 64 * 4)
+#define WG3P_LDS (4 * G3_OP)
 #define WG3P_NST 4  // register stages of the staging waves (must be 4: the prologue and the unrolled loop assume it)
 
-template <bool GROUPED>
 __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, const int by, const int bz,
                                              unsigned char* lds) {
   const int tid = threadIdx.x;
@@ -2139,17 +2138,9 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
   int64_t r_begin = (int64_t)bx * g.rows_per_block;
   int64_t r_end = r_begin + g.rows_per_block;
   if (r_end > g.M) r_end = g.M;
-  float* dW = g.dW;
-  if constexpr (GROUPED) {
-    if (bx >= g.nchunks[0]) return;
-    r_begin = g.chunk_info[3 * bx];
-    r_end = r_begin + g.chunk_info[3 * bx + 1];
-    dW += (int64_t)g.chunk_info[3 * bx + 2] * g.dw_cls_stride;
-  }
+  float* const dW = g.dW;
   if (r_begin >= r_end) return;
   const int64_t nsteps = (r_end - r_begin + BK - 1) / BK;
-  // barriers of the prologue (both groups execute the same number): GROUPED stages two pairs of offset buffers first
-  constexpr int PROLOGUE_BARRIERS = GROUPED ? 7 : 1;
 
   if (wave < 4) {
     // ================================================================ multiply waves
@@ -2162,8 +2153,7 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < PROLOGUE_BARRIERS; ++b) __syncthreads();
+    __syncthreads();  // the staging waves' prologue
     for (int64_t j = 0; j < nsteps; ++j) {
       const unsigned char* const A3 = lds + (j & 1) * 2 * G3_OP;
       const unsigned char* const B3 = A3 + G3_OP;
@@ -2211,7 +2201,6 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
   }
 
   // ================================================================== staging waves
-  unsigned* const offs = reinterpret_cast<unsigned*>(lds + 4 * G3_OP);  // [2][X | Y][32]
   const int lt = tid - 256;
   const int role = lt >> 7;  // 0: dC (dW rows n0..), 1: A (dW columns c0..)
   const int c4 = (lt & 31) * 4, rg = (lt >> 5) & 3;
@@ -2223,31 +2212,14 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // role 0: column sums of dC (bias gradient)
 
   f32x4 v[WG3P_NST][8];  // register stages: the loads of WG3P_NST steps in flight (32 KB per stage and workgroup)
-  unsigned ri = 0u;      // GROUPED: row index of row (lt & 31) of the step whose offsets are written next
 
-  auto index_of = [&](int64_t r0) -> unsigned {
-    const int t = lt & 31;
-    const int64_t pos = r0 + t < r_end ? r0 + t : r_begin;
-    return (unsigned)g.row_index[pos];
-  };
-  auto write_offsets = [&](unsigned row, int ob) {  // every staging wave writes the same 64 words
-    const int t = lt & 31;
-    offs[ob * 64 + t] = row * (unsigned)g.ldx;
-    offs[ob * 64 + 32 + t] = row * (unsigned)g.ldy;
-  };
-  auto load_step = [&](auto PC, int64_t r0, int ob) {
+  auto load_step = [&](auto PC, int64_t r0) {
     constexpr int P = decltype(PC)::value;
     const int64_t left = r_end - (r0 + rg * 8);
     const int nval = (left >= 8 && col_ok) ? 8 : ((left > 0 && col_ok) ? (int)left : 0);
-    if constexpr (GROUPED) {
-      const unsigned* o = offs + ob * 64 + role * 32 + rg * 8;
+    const float* p = base + (r0 + rg * 8) * ld;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[P][j] = *reinterpret_cast<const f32x4*>(j < nval ? base + o[j] : zero);
-    } else {
-      const float* p = base + (r0 + rg * 8) * ld;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[P][j] = *reinterpret_cast<const f32x4*>(j < nval ? p + j * ld : zero);
-    }
+    for (int j = 0; j < 8; ++j) v[P][j] = *reinterpret_cast<const f32x4*>(j < nval ? p + j * ld : zero);
   };
   auto store_step = [&](auto PC, unsigned char* stage) {
     constexpr int P = decltype(PC)::value;
@@ -2269,42 +2241,23 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
     }
   };
   auto row_of = [&](int64_t step) { return r_begin + step * BK; };
-  auto IC = [](auto c) { return c; };
-  (void)IC;
 
-  // ---- prologue: steps 0 .. NST-1 loaded, step 0 split into LDS stage 0, step NST loaded into its register stage.
-  // GROUPED: the offsets are staged two steps at a time (two buffers) in front of the loads that read them; at the end
-  // the offsets of step NST + 1 are in place and the index of step NST + 2 is in flight.
-  {
-    auto round = [&](auto A, auto B, int64_t sa, bool second) {
-      if constexpr (GROUPED) {
-        write_offsets(index_of(row_of(sa)), (int)(sa & 1));
-        write_offsets(index_of(row_of(sa + 1)), (int)((sa + 1) & 1));
-        __syncthreads();
-      }
-      load_step(A, row_of(sa), (int)(sa & 1));
-      if (second) load_step(B, row_of(sa + 1), (int)((sa + 1) & 1));
-      if constexpr (GROUPED) __syncthreads();
-    };
-    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0, true);
-    round(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, 2, true);
-    store_step(std::integral_constant<int, 0>{}, lds);
-    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 4, false);
-    if constexpr (GROUPED) ri = index_of(row_of(WG3P_NST + 2));
-    __syncthreads();
-  }
+  // ---- prologue: steps 0 .. 3 loaded, step 0 split into LDS stage 0, step 4 loaded into its register stage
+  load_step(std::integral_constant<int, 0>{}, row_of(0));
+  load_step(std::integral_constant<int, 1>{}, row_of(1));
+  load_step(std::integral_constant<int, 2>{}, row_of(2));
+  load_step(std::integral_constant<int, 3>{}, row_of(3));
+  store_step(std::integral_constant<int, 0>{}, lds);
+  load_step(std::integral_constant<int, 0>{}, row_of(4));
+  __syncthreads();
 
   // iteration j (K = j % NST): split register stage (K + 1) % NST = step j + 1 into LDS stage (j + 1) & 1, then refill
   // that register stage with step j + 1 + NST
   auto iteration = [&](auto KC, int64_t j) {
     constexpr int K = decltype(KC)::value;
     constexpr int P = (K + 1) % WG3P_NST;
-    if constexpr (GROUPED) {
-      write_offsets(ri, K & 1);                     // offsets of step j + 2 + NST (buffer parity = j & 1)
-      ri = index_of(row_of(j + 3 + WG3P_NST));      // consumed at the start of the next iteration
-    }
     store_step(std::integral_constant<int, P>{}, lds + ((K + 1) & 1) * 2 * G3_OP);
-    load_step(std::integral_constant<int, P>{}, row_of(j + 1 + WG3P_NST), (K + 1) & 1);
+    load_step(std::integral_constant<int, P>{}, row_of(j + 1 + WG3P_NST));
     __syncthreads();
   };
   for (int64_t j = 0; j < nsteps; j += 4) {
@@ -2322,10 +2275,9 @@ __device__ __forceinline__ void wgrad3p_body(const wgrad_args& g, const int bx, 
   }
 }
 
-template <bool GROUPED>
 __global__ void __launch_bounds__(512, 1) k_gemm_wgrad3p(wgrad_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
-  wgrad3p_body<GROUPED>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_w);
+  wgrad3p_body(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_w);
 }
 
 // Several independent weight gradients in ONE launch (a layer's same-shaped dW = g^T a products): blockIdx.x =
@@ -2398,7 +2350,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_wgrad3p_batched(wgrad_batch_arg
 #pragma unroll
   for (int i = 1; i < WGRAD_MAX_BATCH; ++i)
     if (i == prob) g = b.p[i];
-  wgrad3p_body<false>(g, chunk, by, bz, lds_wb);
+  wgrad3p_body(g, chunk, by, bz, lds_wb);
 }
 
 template <typename KERNEL>
@@ -2455,17 +2407,13 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   const bool wsplit = wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32);
   const double wfl = 2.0 * (double)M * N * K;
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD, 4.0 * M * ((double)N + K) + 4.0 * N * K, wfl, wsplit ? 6.0 * wfl : 0.0);
-  if (wsplit && vec && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
+  if (wsplit && vec && !chunk_info && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
     static bool attr_set = false;
     if (!attr_set) {
-      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p<true>));
-      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p<false>));
+      GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p));
       attr_set = true;
     }
-    if (chunk_info)
-      hipLaunchKernelGGL((k_gemm_wgrad3p<true>), grid, dim3(512), WG3P_LDS, h->stream, g);
-    else
-      hipLaunchKernelGGL((k_gemm_wgrad3p<false>), grid, dim3(512), WG3P_LDS, h->stream, g);
+    hipLaunchKernelGGL(k_gemm_wgrad3p, grid, dim3(512), WG3P_LDS, h->stream, g);
   } else if (wsplit) {
     if (chunk_info)
       hipLaunchKernelGGL((k_gemm_wgrad3<true>), grid, dim3(256), 0, h->stream, g);
