@@ -295,6 +295,8 @@ def main():
             torch.cuda.synchronize()
             if args.launch == "auto":
                 def probe(fn, n=8):
+                    for _ in range(2):  # untimed: after the capture the allocator serves eager steps from fresh blocks
+                        fn()
                     torch.cuda.synchronize()
                     t_ = time.perf_counter()
                     for _ in range(n):

@@ -2407,7 +2407,8 @@ static int32_t wgrad_launch(gnx_handle* h, const float* dC, int64_t lddc, const 
   const bool wsplit = wgrad_split_enabled(h, M, rowscale != nullptr) && (!chunk_info || offs32);
   const double wfl = 2.0 * (double)M * N * K;
   gnx_prof_scope prof(h, GNX_K_GEMM_WGRAD, 4.0 * M * ((double)N + K) + 4.0 * N * K, wfl, wsplit ? 6.0 * wfl : 0.0);
-  if (wsplit && vec && !chunk_info && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
+  // (short row ranges -- the readout's 4096-row problems -- keep the two-barrier kernel: 14.7 vs 24 us)
+  if (wsplit && vec && !chunk_info && rows >= 512 && h->opt[GNX_OPT_WGRAD_PIPE] != 0) {
     static bool attr_set = false;
     if (!attr_set) {
       GNX_HIP(wgrad3p_attr(&k_gemm_wgrad3p));
