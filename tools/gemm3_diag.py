@@ -1,4 +1,6 @@
-"""Timing of the tiled multi-segment GEMM on the three PNA shapes that use it (cfg-2 sizes)."""
+"""Timing of the tiled multi-segment GEMM on the three PNA shapes that use it (cfg-2 sizes; DIAG_M = rows).
+DIAG_MODES: 2 = split operands, software-pipelined kernel where eligible (default build), 1 = split operands, two-barrier
+kernel (GNX_OPT_GEMM_PIPE = 0), 0 = fp32 MFMA (GNX_OPT_GEMM_SPLIT = 0)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnepcsaft_amd import _lib, ops
@@ -15,7 +17,7 @@ cases = {
     "dx    NN K=384 N=128": (lambda: ops.gemm([(g, None, Wp[:, :F]), (dP, None, W0[:, :F]), (dQ, None, W0[:, F:2 * F])], z, b_trans=False), (M * 4 * F) * 4, 2 * M * 3 * F * F),
 }
 for name, (fn, byts, flops) in cases.items():
-    for mode in (os.environ.get("DIAG_MODES", "1,0").split(",")):
+    for mode in (os.environ.get("DIAG_MODES", "2,1,0").split(",")):
         ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_SPLIT, 1 if int(mode) else 0)
         ops.set_option(torch.device("cuda:0"), _lib.OPT_GEMM_PIPE, 1 if int(mode) == 2 else 0)
         for _ in range(5): fn()
