@@ -11,7 +11,6 @@ for mode in os.environ.get("DIAG_MODES", "2,1,0").split(","):
     mode = int(mode)
     ops.set_option(dev, _lib.OPT_GEMM_SPLIT, 1 if mode else 0)
     ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1 if mode == 2 else 0)
-    ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1 if mode == 2 else 0)
     res = []
     for K in (384, 768, 1536):
         A = torch.randn(M, K, device=dev); W = torch.randn(F, K, device=dev); z = torch.empty(M, F, device=dev)
