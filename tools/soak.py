@@ -8,10 +8,13 @@ from gnnepcsaft_amd.optim import configure_fused_optimizers
 from gnnepcsaft_amd.train.models import create_model
 
 dev = torch.device("cuda:0")
-cfg = default_config(2)
+gen = int(os.environ.get("CONFIG", "2"))           # 2: 20-atom molecules, 5: skewed 5..80 atoms
+cfg = default_config(gen)
 steps = int(os.environ.get("STEPS", "300"))
-batches = [synthetic_batch(2048, 2, seed=100 + i).to(dev) for i in range(4)]
-deg = calc_deg([synthetic_batch(2048, 2)])
+# four batches of different sizes: every step changes the row counts (ragged tiles, different kernel dispatches)
+sizes = [int(v) for v in os.environ.get("BATCHES", "2048,4096,1536,3000").split(",")]
+batches = [synthetic_batch(n, gen, seed=100 + i).to(dev) for i, n in enumerate(sizes)]
+deg = calc_deg([synthetic_batch(2048, gen)])
 torch.manual_seed(0)
 model = create_model(cfg, deg).to(dev)
 model.train()
@@ -36,5 +39,5 @@ for i in range(steps):
         free, total = torch.cuda.mem_get_info()
         print(f"step {i}: loss {losses[-1]:.5f}  torch allocated {mem[-1]:.1f} MiB  device used {(total-free)/2**20:.0f} MiB", flush=True)
 assert losses[-1] < losses[0], (losses[0], losses[-1])
-assert abs(mem[-1] - mem[1]) < 1.0, mem
+assert abs(mem[-1] - mem[2]) < 64.0, mem  # batches of four sizes: the caching allocator settles after one round
 print("soak ok")
