@@ -17,7 +17,9 @@ timing barrier.  ``--dry-run`` rehearses the launch / barrier / exchange protoco
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
   roofline     — the scatter-aggregate kernel (gnx_pna_aggregate_fwd): algorithmic bytes per launch / its average
-                 duration, timed live with HIP events on the launch stream during the timed steps, vs 8 TB/s HBM;
+                 duration, timed live with HIP events attached to the kernel's dispatch on the launch stream
+                 (hipExtLaunchKernelGGL start / stop events: the kernel's own execution time, the quantity rocprofv3's
+                 kernel trace reports) during the instrumented steps, vs 8 TB/s HBM;
   cpu_baseline — the oracle (pure-torch restatement of the reference's PyG CPU path, kind "port") timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -428,12 +430,13 @@ def main():
                                          if flat._overlap else ("rccl, one call after backward" if flat.collective
                                                                 else "none (1 rank)"))},
             "loss": loss_val,
-            # the scatter-aggregate kernel: algorithmic bytes per launch / average launch duration (HIP events on the
-            # launch stream, as run); "bwd" carries both the as-run (two streams) and the isolated duration; "large"
+            # the scatter-aggregate kernel: algorithmic bytes per launch / average launch duration (HIP events attached
+            # to the dispatch on the launch stream, as run); "bwd" carries both the as-run (two streams) and the isolated duration; "large"
             # is the same forward kernel on cfg-4's per-GPU batch, whose 1.0 GB per launch does not fit the Infinity Cache
             "roofline": {"bound": "hbm", "kernel": "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd",
                          "achieved": f_run["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_run["gbs"] / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": f_run["bytes"], "avg_us": f_run["avg_us"],
+                         "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL start/stop)",
                          "launches": f_run["launches"], "avg_us_isolated": f_iso["avg_us"],
                          "bwd": {"alg_bytes_per_launch": b_run["bytes"], "avg_us": b_run["avg_us"], "achieved": b_run["gbs"],
                                  "frac": b_run["gbs"] / HBM_PEAK_GBS, "avg_us_isolated": b_iso["avg_us"],

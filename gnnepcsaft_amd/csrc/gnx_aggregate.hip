@@ -127,15 +127,15 @@ extern "C" int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const in
   GNX_CHECK_ARG(N == 0 || A, "gnx_pna_aggregate_fwd: A is NULL");
   if (N == 0) return GNX_OK;
   // algorithmic bytes: read the messages 4EH and the index 4E, write the four aggregates 16NH
-  gnx_prof_scope prof(h, GNX_K_PNA_AGG_FWD, 4.0 * E * T * F + 4.0 * E + 16.0 * N * T * F);
+  gnx_prof_scope prof(h, GNX_K_PNA_AGG_FWD, 4.0 * E * T * F + 4.0 * E + 16.0 * N * T * F, 0.0, 0.0, true);
   if (F % 4 == 0) {
     int64_t th = N * (T * F / 4);
-    hipLaunchKernelGGL(k_pna_agg_fwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, m, rowptr, N, (int)T,
-                       (int)F, A);
+    GNX_LAUNCH_TIMED(prof, k_pna_agg_fwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, m, rowptr, N,
+                     (int)T, (int)F, A);
   } else {
     int64_t th = N * (T * F);
-    hipLaunchKernelGGL(k_pna_agg_fwd<1>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, m, rowptr, N, (int)T,
-                       (int)F, A);
+    GNX_LAUNCH_TIMED(prof, k_pna_agg_fwd<1>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, m, rowptr, N,
+                     (int)T, (int)F, A);
   }
   GNX_LAUNCH_CHECK();
   return GNX_OK;
@@ -318,27 +318,27 @@ extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const f
   GNX_CHECK_ARG(N == 0 || (dA && A), "gnx_pna_aggregate_bwd: NULL argument");
   if (N == 0) return GNX_OK;
   // read the aggregate gradient 16NH, re-read the messages 4EH + index 4E, write the message gradient 4EH
-  gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD, 16.0 * N * T * F + 8.0 * E * T * F + 4.0 * E);
+  gnx_prof_scope prof(h, GNX_K_PNA_AGG_BWD, 16.0 * N * T * F + 8.0 * E * T * F + 4.0 * E, 0.0, 0.0, true);
   {
     if (h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] != 0) {
       if (F % 4 == 0)
-        hipLaunchKernelGGL(k_pna_agg_bwd_rc<4>, dim3((unsigned)gnx_cdiv(N * (T * F / 4), 256)), dim3(256), 0, h->stream,
-                           dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+        GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd_rc<4>, dim3((unsigned)gnx_cdiv(N * (T * F / 4), 256)), dim3(256), 0,
+                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
       else
-        hipLaunchKernelGGL(k_pna_agg_bwd_rc<1>, dim3((unsigned)gnx_cdiv(N * (int64_t)(T * F), 256)), dim3(256), 0,
-                           h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+        GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd_rc<1>, dim3((unsigned)gnx_cdiv(N * (int64_t)(T * F), 256)), dim3(256), 0,
+                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
       GNX_LAUNCH_CHECK();
       return GNX_OK;
     }
   }
   if (F % 4 == 0) {
     int64_t th = N * (T * F / 4);
-    hipLaunchKernelGGL(k_pna_agg_bwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr, N,
-                       (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+    GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd<4>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr,
+                     N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
   } else {
     int64_t th = N * (T * F);
-    hipLaunchKernelGGL(k_pna_agg_bwd<1>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr, N,
-                       (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+    GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd<1>, dim3((unsigned)gnx_cdiv(th, 256)), dim3(256), 0, h->stream, dA, m, A, rowptr,
+                     N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
   }
   GNX_LAUNCH_CHECK();
   return GNX_OK;
@@ -558,13 +558,13 @@ extern "C" int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const f
   if (N == 0) return GNX_OK;
   GNX_CHECK_ARG(x && Le && rowptr && out, "gnx_gine_aggregate_fwd: NULL argument");
   // gather x[src] per edge 4EH + two indices 8E, read x and write out 8NH
-  gnx_prof_scope prof(h, GNX_K_GINE_AGG_FWD, 4.0 * E * H + 8.0 * E + 8.0 * N * H);
+  gnx_prof_scope prof(h, GNX_K_GINE_AGG_FWD, 4.0 * E * H + 8.0 * E + 8.0 * N * H, 0.0, 0.0, true);
   if (H % 4 == 0)
-    hipLaunchKernelGGL(k_gine_fwd<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, x, Le, rowptr,
-                       src, code, N, (int)H, eps, out);
+    GNX_LAUNCH_TIMED(prof, k_gine_fwd<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, x, Le,
+                     rowptr, src, code, N, (int)H, eps, out);
   else
-    hipLaunchKernelGGL(k_gine_fwd<1>, dim3((unsigned)gnx_cdiv(N * H, 256)), dim3(256), 0, h->stream, x, Le, rowptr, src,
-                       code, N, (int)H, eps, out);
+    GNX_LAUNCH_TIMED(prof, k_gine_fwd<1>, dim3((unsigned)gnx_cdiv(N * H, 256)), dim3(256), 0, h->stream, x, Le, rowptr,
+                     src, code, N, (int)H, eps, out);
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
@@ -719,13 +719,15 @@ extern "C" int32_t gnx_gine_aggregate_bwd(gnx_handle* h, const float* dout, cons
   GNX_CHECK_ARG(dout && x && Le && colptr && dx, "gnx_gine_aggregate_bwd: NULL argument");
   GNX_CHECK_ARG(E == 0 || (cpos && src && dst && code), "gnx_gine_aggregate_bwd: NULL edge array with E>0");
   // dx: gather dout[dst] per edge 4EH + indices 8E, read dout and x, write dx 12NH; dLe: another 8EH of gathers
-  gnx_prof_scope prof(h, GNX_K_GINE_AGG_BWD, 4.0 * E * H + 8.0 * E + 12.0 * N * H + (dLe ? 8.0 * E * H : 0.0));
+  // (one launch when the bond-table gradient is computed elsewhere: its events are then attached to the dispatch)
+  gnx_prof_scope prof(h, GNX_K_GINE_AGG_BWD, 4.0 * E * H + 8.0 * E + 12.0 * N * H + (dLe ? 8.0 * E * H : 0.0), 0.0, 0.0,
+                      dLe == nullptr || E == 0);
   if (H % 4 == 0)
-    hipLaunchKernelGGL(k_gine_bwd_dx<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, dout, x, Le,
-                       colptr, cpos, dst, code, N, (int)H, eps, dx);
+    GNX_LAUNCH_TIMED(prof, k_gine_bwd_dx<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, dout, x,
+                     Le, colptr, cpos, dst, code, N, (int)H, eps, dx);
   else
-    hipLaunchKernelGGL(k_gine_bwd_dx<1>, dim3((unsigned)gnx_cdiv(N * H, 256)), dim3(256), 0, h->stream, dout, x, Le,
-                       colptr, cpos, dst, code, N, (int)H, eps, dx);
+    GNX_LAUNCH_TIMED(prof, k_gine_bwd_dx<1>, dim3((unsigned)gnx_cdiv(N * H, 256)), dim3(256), 0, h->stream, dout, x, Le,
+                     colptr, cpos, dst, code, N, (int)H, eps, dx);
   GNX_LAUNCH_CHECK();
   if (dLe != nullptr && E > 0) {
     GNX_CHECK_ARG(R > 0, "gnx_gine_aggregate_bwd: R <= 0");

@@ -1,6 +1,7 @@
 // Internal helpers shared by the gnx_*.hip translation units (gfx950 only; no dual paths).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -62,11 +63,18 @@ void gnx_set_error(const char* fmt, ...);
   } while (0)
 
 // Records an event pair around the launches issued while it is alive, if the handle profiles kernel `kid`.
+// `dispatch_timed`: the scope holds exactly ONE kernel launch and its two events are attached to that dispatch
+// (GNX_LAUNCH_TIMED -> hipExtLaunchKernelGGL start / stop events): their distance is the kernel's own execution time,
+// the quantity rocprofv3's kernel trace reports, without the ~3-4 us of marker packets and dispatch latency that an
+// event pair recorded AROUND a launch includes.
 struct gnx_prof_scope {
   gnx_handle* h;
   bool on;
-  gnx_prof_scope(gnx_handle* h_, int kid, double bytes = 0.0, double flops = 0.0, double mfma = 0.0)
-      : h(h_), on(((h_->prof_mask >> kid) & 1u) != 0 && kid != GNX_K_NONE) {
+  bool dispatch_timed;
+  hipEvent_t e_start = nullptr, e_stop = nullptr;
+  gnx_prof_scope(gnx_handle* h_, int kid, double bytes = 0.0, double flops = 0.0, double mfma = 0.0,
+                 bool dispatch_timed_ = false)
+      : h(h_), on(((h_->prof_mask >> kid) & 1u) != 0 && kid != GNX_K_NONE), dispatch_timed(dispatch_timed_) {
     if (on) {
       const size_t i = h->ev_used / 2;
       if (h->ev_kid.size() <= i) h->ev_kid.resize(i + 1);
@@ -75,24 +83,45 @@ struct gnx_prof_scope {
       h->ev_work[3 * i] = bytes;
       h->ev_work[3 * i + 1] = flops;
       h->ev_work[3 * i + 2] = mfma;
-      mark();
+      if (dispatch_timed) {
+        e_start = take();
+        e_stop = take();
+        if (!e_start || !e_stop) on = false;
+      } else {
+        mark();
+      }
     }
   }
   ~gnx_prof_scope() {
-    if (on) mark();
+    if (on && !dispatch_timed) mark();
   }
-  void mark() {
+  hipEvent_t take() {  // the next event of the handle's pool, not recorded
     if (h->ev_used == h->ev.size()) {
       hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) {
-        on = false;
-        return;
-      }
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
       h->ev.push_back(e);
     }
-    (void)hipEventRecord(h->ev[h->ev_used++], h->stream);
+    return h->ev[h->ev_used++];
+  }
+  void mark() {
+    hipEvent_t e = take();
+    if (!e) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(e, h->stream);
   }
 };
+
+// One kernel launch inside a dispatch_timed scope: with profiling on, the scope's events are attached to the dispatch;
+// otherwise an ordinary launch (also what a stream capture sees).
+#define GNX_LAUNCH_TIMED(prof, kernel, grid, block, shmem, stream, ...)                                        \
+  do {                                                                                                         \
+    if ((prof).on && (prof).dispatch_timed)                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (prof).e_start, (prof).e_stop, 0, __VA_ARGS__); \
+    else                                                                                                       \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
+  } while (0)
 
 static inline int64_t gnx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
