@@ -248,6 +248,8 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
     mn[v] = INFINITY;
     mx[v] = -INFINITY;
   }
+  // (measured and rejected, round 2: keeping the node's first 8 messages in registers for the three passes -- 71 vs 67 us at
+  // cfg-2, 0.43 vs 0.59 of HBM as run at cfg-5: the extra 32 VGPRs cost more occupancy than the L1-resident re-reads cost)
   const float* mp = m + (int64_t)p0 * H + c;
   for (int p = p0; p < p1; ++p, mp += H) {  // same order and roundings as k_pna_agg_fwd
     float a[VEC];
