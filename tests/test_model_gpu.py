@@ -272,4 +272,6 @@ def test_native_layer_backward_equals_the_python_launch_sequence(gpu_device, kw,
     ref_loss, ref = results[(False, False)]
     for key, (l, g) in results.items():
         assert l == ref_loss, key
-        assert rel_err(g, ref) <= 2e-6, (key, rel_err(g, ref))
+        # the weight gradients are accumulated with fp32 atomics: two runs of the SAME launch sequence differ by 1-2e-6
+        # (max-norm) from the order of the atomic adds alone; a missing or misplaced launch shows at >= 1e-3
+        assert rel_err(g, ref) <= 5e-6, (key, rel_err(g, ref))
