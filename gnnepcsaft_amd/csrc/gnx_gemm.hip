@@ -545,6 +545,15 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 //     instead of eight) each changed nothing (25.1 vs 25.2-26.4 us at 81 920 rows, 42-44 vs 40-43 us at 163 840): the
 //     kernel moves 64 KB per 64-row tile and CU in 4.1-4.5 us = 14-16 GB/s per CU of mixed read + write traffic, and
 //     that -- not latency, issue order or the matrix pipe (96 MFMAs per SIMD and tile = 1.3-1.7 us) -- is its bound.
+//     Also measured and rejected: the same kernel as TWO 256-thread workgroups per CU (wave = 64 rows x 32 columns, one LDS
+//     stage each, two barriers per tile; built on the idea that the eight waves of this workgroup are barrier-locked into
+//     the same phase): bit-identical, 26.7 vs 25.2 us at 81 920 rows, 91.5 vs 87.7 us at 327 680.  With the C stores
+//     removed this kernel needs 3.3 us per tile (67 vs 86 us at 327 680 rows), i.e. the on-CU work of a tile -- 96 MFMAs
+//     per SIMD (1.3-1.7 us) + the split of 2 x 16 floats per lane (0.6 us) + 48 KB of LDS stores + 192 KB of fragment
+//     reads -- adds up whoever issues it: tools/ubench/wave_specialised_overlap.hip shows the same for different waves of one
+//     SIMD (0.91 us of MFMAs + 0.84 us of split and LDS stores -> 1.41-1.46 us together).  The split-operand formulation
+//     itself, not this kernel's structure, sets the per-tile time; what would remove work is a producer that writes the
+//     three bf16 images instead of fp32 (no split, half the staging LDS traffic in every consumer).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define W3_BM 64
