@@ -4,6 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o wave_specialised_overlap wave_specialised_overlap.hip
 // MI355X, round 2 (us per step, all CUs, random operands): barrier only 0.02; multiply waves only 0.91 (0.87 with fragment
 // reads); staging waves only 0.60 (split) / 0.84 (+ LDS stores); both 1.04 / 1.41 / 1.46 (MFMA + split / + stores / + reads).
+// With -fno-slp-vectorize (no packed-f32 VALU in the split): staging alone 0.60 / 1.02, both 1.04 / 1.24 / 1.30.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
