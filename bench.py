@@ -273,8 +273,13 @@ def main():
         graph_step = None
         try:
             flat.enable_overlap(False)  # collectives cannot be captured: one exchange after the replay instead
+            flat.finish()
+            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=main_stream):
+            # thread_local: with a process group alive, ProcessGroupNCCL's watchdog thread polls its events at any time; in
+            # the default (global) mode such a call from ANOTHER thread during the capture aborts the process
+            # (hipErrorStreamCaptureUnsupported -- seen once in tests/test_dp_gpu.py)
+            with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
                 static_loss = step_body()
 
             def graph_step():

@@ -149,7 +149,8 @@ class InferenceEngine:
                     self(sx, se, sa, None, validate=False)
             torch.cuda.current_stream(self.device).wait_stream(stream)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            # thread_local: another thread's HIP call (a process group's watchdog) must not abort the capture
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 out = self(sx, se, sa, None, validate=False)
             slot = self._graphs[key] = (graph, sx, se, sa, out)
             if len(self._graphs) > 256:  # bounded cache: drop the oldest shape
