@@ -22,6 +22,10 @@ VARIANTS = {
     "wgs1024": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 1024),
     "wgs96": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 96),
     "wgs128": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 128),
+    "wgs64": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 64),
+    "wgs160": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 160),
+    "wgs128rows2048": lambda dev: (ops.set_option(dev, _lib.OPT_WGRAD_WGS, 128), setattr(ops.DegreeClasses, "WGRAD_ROWS", 2048)),
+    "wgs128rows512": lambda dev: (ops.set_option(dev, _lib.OPT_WGRAD_WGS, 128), setattr(ops.DegreeClasses, "WGRAD_ROWS", 512)),
     "wgs192": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 192),
     "wgs384": lambda dev: ops.set_option(dev, _lib.OPT_WGRAD_WGS, 384),
     "rows4096": lambda dev: setattr(ops.DegreeClasses, "WGRAD_ROWS", 4096),
