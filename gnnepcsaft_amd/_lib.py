@@ -10,22 +10,23 @@ import torch
 
 _LIB_PATH = Path(__file__).resolve().parent / "libgnnepcsaft_hip.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
 # gnx_set_option ids (include/gnx.h)
 OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
-    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE = range(10)
+    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED = range(11)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
     K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD, K_GEMM_TILED, K_GEMM_SMALL, K_GEMM_WGRAD_BATCHED, K_KEY_SEGMENT_SUM, \
-    K_EMBED = range(16)
-K_COUNT = 16
+    K_EMBED, K_PNA_EDGE_FWD = range(17)
+K_COUNT = 17
 KERNEL_GROUPS = {K_PNA_AGG_FWD: "pna_aggregate_fwd", K_PNA_AGG_BWD: "pna_aggregate_bwd", K_GEMM_WS: "gemm_weights_stationary",
                  K_GEMM_WGRAD: "weight_gradient", K_GINE_AGG_FWD: "gine_aggregate_fwd", K_GINE_AGG_BWD: "gine_aggregate_bwd",
                  K_EDGE_COMBINE_FWD: "edge_combine_fwd", K_EDGE_COMBINE_BWD: "edge_combine_bwd", K_BN_FWD: "batchnorm_fwd",
                  K_BN_BWD: "batchnorm_bwd", K_GEMM_TILED: "gemm_tiled", K_GEMM_SMALL: "gemm_small",
-                 K_GEMM_WGRAD_BATCHED: "weight_gradient_batched", K_KEY_SEGMENT_SUM: "key_segment_sum", K_EMBED: "embedding"}
+                 K_GEMM_WGRAD_BATCHED: "weight_gradient_batched", K_KEY_SEGMENT_SUM: "key_segment_sum", K_EMBED: "embedding",
+                 K_PNA_EDGE_FWD: "pna_edge_fused_fwd"}
 
 
 class GnxError(RuntimeError):
@@ -57,7 +58,8 @@ class PnaFwdArgs(C.Structure):
                 ("rowptr", _vp), ("src", _vp), ("dst", _vp), ("code", _vp), ("dperm", _vp), ("tiles", _vp), ("ntiles", _vp),
                 ("max_tiles", _i64), ("x", _vp), ("Te", _vp), ("weff", _vp * PNA_MAX_TOWERS), ("Wm", _vp), ("bm", _vp),
                 ("params", C.POINTER(_vp)), ("P", _vp), ("Q", _vp), ("A", _vp), ("hs", _vp * PNA_MAX_LAYERS),
-                ("zs", _vp * PNA_MAX_LAYERS), ("ws", _vp), ("ws_bytes", _sz), ("out", _vp)]
+                ("zs", _vp * PNA_MAX_LAYERS), ("ws", _vp), ("ws_bytes", _sz), ("out", _vp), ("etile_info", _vp),
+                ("etile_w", _i32), ("_pad", _i32)]
 
 
 class PnaBwdArgs(C.Structure):
@@ -118,6 +120,10 @@ SIGNATURES = {
     "gnx_edge_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz]),
     "gnx_pna_aggregate_fwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "gnx_pna_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gnx_edge_tiles_count": (_i32, [_i64, _i32]),
+    "gnx_edge_tiles": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    "gnx_pna_edge_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, C.POINTER(_vp),
+                                C.POINTER(_vp), _vp, _vp, _vp]),
     "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "gnx_gine_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                       _vp, _vp]),

@@ -16,7 +16,7 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libgnnepcsaft_hip.so"
 OBJ_DIR = PKG / "csrc" / "build"
-SOURCES = ["gnx_api.hip", "gnx_pack.hip", "gnx_embed.hip", "gnx_gemm.hip", "gnx_aggregate.hip", "gnx_norm.hip", "gnx_optim.hip", "gnx_layer.hip"]
+SOURCES = ["gnx_api.hip", "gnx_pack.hip", "gnx_embed.hip", "gnx_gemm.hip", "gnx_aggregate.hip", "gnx_norm.hip", "gnx_optim.hip", "gnx_layer.hip", "gnx_fused.hip"]
 # -fno-slp-vectorize: the SLP vectoriser turns the fp32 -> 3 x bf16 split into packed-f32 VALU (v_pk_add_f32), which issues
 # badly beside MFMAs (tools/ubench/wave_specialised_overlap.hip: 1.41 -> 1.24 us per step without it); cfg-2 step 7.89 -> 7.77 ms
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(r.stderr, file=sys.stderr)
         return str(obj)
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs], capture_output=True,
                        text=True)

@@ -48,7 +48,7 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
               {GNX_OPT_WGRAD_WGS, "GNX_WGRAD_WGS", 0},         {GNX_OPT_AGG_BWD_RECOMPUTE, "GNX_AGG_BWD_RECOMPUTE", 1},
               {GNX_OPT_EMBED_BWD_MFMA, "GNX_EMBED_BWD_MFMA", 1}, {GNX_OPT_STD_BWD_CENTERED, "GNX_STD_BWD_CENTERED", 1},
               {GNX_OPT_GEMM_PIPE, "GNX_GEMM_PIPE", 1},
-              {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1}};
+              {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1},       {GNX_OPT_EDGE_FUSED, "GNX_EDGE_FUSED", 1}};
   for (const auto& o : opts) {
     const char* e = getenv(o.env);
     h->opt[o.id] = e ? atoi(e) : o.def;

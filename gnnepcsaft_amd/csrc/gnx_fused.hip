@@ -1,0 +1,401 @@
+// Fused PNA edge pipeline: message assembly -> pre-layer 1 -> mean|min|max|std aggregate in ONE kernel per layer.
+//
+// Reference semantics: [3P] torch_geometric.nn.PNAConv.message + DegreeScalerAggregation as built at
+// /root/reference/gnnepcsaft/train/models.py:445-457 with pre_layers = 2 (configs/default.py:44):
+//     h1[p] = relu(P[dst[p]] + Q[src[p]] + Te[code[p]])      (pre-layer 0 folded to node level, gnx_edge_combine_fwd)
+//     m[p]  = h1[p] W1^T + b1                                  (pre-layer 1, no activation: the last pre layer)
+//     A[n]  = [mean | min | max | std] over the CSR row of n   (gnx_pna_aggregate_fwd)
+// The unfused launch sequence moves h1 and m through HBM twice each (edge_combine 213 MB -> k_gemm_ws3 158 MB ->
+// k_pna_agg_fwd 253 MB per cfg-2 layer by PMC).  Here a persistent workgroup walks EDGE TILES of whole destination
+// rows: it gathers the three operand rows straight into the split-bf16 LDS images of the product (no h1 read), multiplies
+// by the weights it holds in registers (the k_gemm_ws3 body), parks the fp32 result tile in LDS and reduces the CSR rows it
+// already holds -- m is written once (backward needs it), never read back.
+//
+// Bit-exactness: h1 is computed with k_edge_combine_fwd's expression, the product with k_gemm_ws3's MFMA sequence and
+// accumulator order, the aggregate with k_pna_agg_fwd's operation order over the same rows, so h1 / m / A are bit-identical
+// to the unfused path's (tests/test_fused_gpu.py).
+//
+// Edge tiles (gnx_edge_tiles): tile j holds every node whose FIRST CSR position lies in [W j, W (j + 1)); with in-degrees
+// <= maxdeg and W = 65 - maxdeg a tile never exceeds 64 message rows.  A violated bound (a degree above the hint) sets
+// sticky range-flag bit 6 and the overflowing rows are dropped (no out-of-bounds access).
+#include "gnx_common.hpp"
+#include "gnx_split.hpp"
+
+#include <cmath>
+
+#define STD_VAR_MIN 1e-5f
+#define STD_MASK_AT 0.0031622776601683794f
+
+#define EF_BM 64
+#define EF_LDC 132                            // floats per row of the fp32 message tile (33 x 16 B: odd)
+#define EF_A_BYTES (2 * W3_BUF)               // two stages of three bf16 images [64][128 (+8)]
+#define EF_C_BYTES (EF_BM * EF_LDC * 4)
+#define EF_LDS (EF_A_BYTES + EF_C_BYTES)      // 138 240 B: one workgroup per CU
+
+struct edge_fwd_args {
+  const float* P;
+  const float* Q;
+  const float* Te;
+  const int* src;
+  const int* dst;
+  const int* code;
+  const int* rowptr;
+  const int* tile_info;  // (first node, first CSR position) per tile, ntiles + 1 entries
+  int ntiles, T, F, H;
+  int64_t N, E;
+  const float* W[GNX_PNA_MAX_TOWERS];  // pre-layer 1 weight [F, F] ([out, in]) per tower
+  const float* b[GNX_PNA_MAX_TOWERS];
+  float* h1;  // [E, H] or NULL
+  float* m;   // [E, H] or NULL
+  float* A;   // [N, T, 4F]
+  int* flag;
+};
+
+__global__ void k_edge_tiles(const int* __restrict__ rowptr, int64_t N, int64_t E, int W, int ntiles,
+                             int* __restrict__ info) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > ntiles) return;
+  if (j == ntiles) {
+    info[2 * j] = (int)N;
+    info[2 * j + 1] = (int)E;
+    return;
+  }
+  const int64_t target = (int64_t)W * j;  // <= E by the choice of ntiles
+  int lo = 0, hi = (int)N;                // first n in [0, N] with rowptr[n] >= target (rowptr[N] = E)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rowptr[mid] >= target) hi = mid;
+    else lo = mid + 1;
+  }
+  info[2 * j] = lo;
+  info[2 * j + 1] = rowptr[lo];
+}
+
+extern "C" int32_t gnx_edge_tiles_count(int64_t E, int32_t tile_w) { return tile_w > 0 ? (int32_t)(E / tile_w) + 1 : 0; }
+
+extern "C" int32_t gnx_edge_tiles(gnx_handle* h, const int32_t* rowptr, int64_t N, int64_t E, int32_t tile_w,
+                                  int32_t* tile_info) {
+  GNX_CHECK_ARG(h && rowptr && tile_info && N >= 0 && E >= 0 && tile_w >= 1 && tile_w <= EF_BM,
+                "gnx_edge_tiles: bad argument (tile_w must be in [1, 64])");
+  const int ntiles = gnx_edge_tiles_count(E, tile_w);
+  hipLaunchKernelGGL(k_edge_tiles, dim3((unsigned)gnx_cdiv(ntiles + 1, 256)), dim3(256), 0, h->stream, rowptr, N, E,
+                     (int)tile_w, ntiles, tile_info);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}
+
+__global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* Cs = reinterpret_cast<float*>(lds + EF_A_BYTES);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const int F = g.F, H = g.H, T = g.T;
+  const int nslab = (F + 15) >> 4;
+  const int gc = wc + li;
+  const int tw = blockIdx.x % T;       // this workgroup's tower (the grid is a multiple of T)
+  const int tstride = gridDim.x / T;
+  const int coff = tw * F;
+
+  // loader / aggregation mapping: 32 lanes cover one 512-B row with consecutive float4, 16 rows per pass
+  const int ar = tid >> 5, ak = (tid & 31) * 4;
+  const bool ak_ok = ak < F;
+  const int akc = ak_ok ? ak : 0;
+  const int2* tinfo = reinterpret_cast<const int2*>(g.tile_info);
+  const int last = g.ntiles - 1;
+  const int Em1 = (int)(g.E - 1);
+
+  struct bounds {
+    int n0, e0, n1, e1;
+  };
+  auto load_bounds = [&](int j) {
+    const int jj = j < last ? j : last;  // clamped: tiles past the end are never processed, their loads stay in range
+    const int2 a = tinfo[jj], c = tinfo[jj + 1];
+    bounds b = {a.x, a.y, c.x, c.y};
+    return b;
+  };
+  auto count_of = [&](const bounds& b) {
+    const int c = b.e1 - b.e0;
+    return c < EF_BM ? c : EF_BM;
+  };
+
+  int idx[4][3];  // dst, src, code of rows ar + 16 i of the tile whose gather is issued next
+  auto load_idx = [&](const bounds& b) {
+    const int cm1 = count_of(b) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ar + 16 * i;
+      int e = b.e0 + (r < cm1 ? r : (cm1 > 0 ? cm1 : 0));
+      e = e < Em1 ? e : Em1;
+      idx[i][0] = g.dst[e];
+      idx[i][1] = g.src[e];
+      idx[i][2] = g.code[e];
+    }
+  };
+  f32x4 ga[4][3];
+  auto issue_gather = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ga[i][0] = *reinterpret_cast<const f32x4*>(g.P + (int64_t)idx[i][0] * H + coff + akc);
+      ga[i][1] = *reinterpret_cast<const f32x4*>(g.Q + (int64_t)idx[i][1] * H + coff + akc);
+      ga[i][2] = *reinterpret_cast<const f32x4*>(g.Te + (int64_t)idx[i][2] * H + coff + akc);
+    }
+  };
+  // CSR bounds of the first two nodes this thread aggregates
+  auto load_rp = [&](const bounds& b, int (&r)[2][2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t node = (int64_t)b.n0 + ar + 16 * k;
+      r[k][0] = g.rowptr[node < g.N ? node : g.N];
+      r[k][1] = g.rowptr[node + 1 < g.N ? node + 1 : g.N];
+    }
+  };
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  // gathered rows -> h1 (k_edge_combine_fwd's expression) -> global h1 + three bf16 images of LDS stage `buf`
+  auto consume_gather = [&](const bounds& b, unsigned char* buf) {
+    const int cnt = count_of(b);
+    f32x4 hv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = ak_ok && (ar + 16 * i) < cnt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r = (ga[i][0][j] + ga[i][1][j]) + ga[i][2][j];
+        hv[i][j] = ok ? fmaxf(r, 0.f) : 0.f;
+      }
+      if (ok && g.h1 != nullptr)
+        *reinterpret_cast<f32x4*>(g.h1 + (int64_t)(b.e0 + ar + 16 * i) * H + coff + ak) = hv[i];
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {  // rows ar + 32 hh and ar + 32 hh + 16: one split3 of 8 values
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[4 * q + j] = hv[2 * hh + q][j];
+      bf16x8 pc[3];
+      split3(x, pc[0], pc[1], pc[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+        unsigned char* q = buf + p * W3_PIECE + (ar + 32 * hh) * W3_LDB + ak * 2;
+        *reinterpret_cast<f32x2*>(q) = f32x2{w.x, w.y};
+        *reinterpret_cast<f32x2*>(q + 16 * W3_LDB) = f32x2{w.z, w.w};
+      }
+    }
+  };
+
+  const float bv = (gc < F) ? g.b[tw][gc] : 0.f;
+  int j = blockIdx.x / T;  // grid <= ntiles * T
+  bounds B0 = load_bounds(j), B1 = load_bounds(j + tstride), B2 = load_bounds(j + 2 * tstride);
+  load_idx(B0);
+  issue_gather();  // in flight while the weight fragments are fetched and split
+  int R0[2][2];
+  load_rp(B0, R0);
+
+  // ---- this wave's pre-layer-1 weight fragments, split once: lane holds column gc, k = 16 s + 8 lh + jj
+  bf16x8 b1[8], b2[8], b3[8];
+  {
+    const float* Wt = g.W[tw];
+    const bool n_ok = gc < F;
+    const int gcc = n_ok ? gc : 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float x[8];
+      const int k0 = 16 * s + 8 * lh;
+      const int ka = (k0 < F) ? k0 : 0, kb = (k0 + 4 < F) ? k0 + 4 : 0;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(Wt + (int64_t)gcc * F + ka);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(Wt + (int64_t)gcc * F + kb);
+      const bool ok0 = n_ok && k0 < F, ok1 = n_ok && k0 + 4 < F;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        x[jj] = ok0 ? v0[jj] : 0.f;
+        x[4 + jj] = ok1 ? v1[jj] : 0.f;
+      }
+      split3(x, b1[s], b2[s], b3[s]);
+    }
+  }
+  consume_gather(B0, lds);
+  load_idx(B1);
+  __syncthreads();
+
+  int cur = 0;
+  while (j < g.ntiles) {
+    const int j1 = j + tstride;
+    const bool has1 = j1 < g.ntiles;
+    int R1[2][2] = {{0, 0}, {0, 0}};
+    if (has1) {  // wave-uniform; the gather of tile j1 stays in flight under the MFMAs below
+      issue_gather();
+      load_rp(B1, R1);
+    }
+    load_idx(B2);  // tile j + 2 (clamped bounds past the end: harmless loads)
+    const bounds B3 = load_bounds(j1 + 2 * tstride);
+    if (tid == 0 && B0.e1 - B0.e0 > EF_BM) atomicOr(g.flag, 64);
+
+    f32x16 acc, corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = 0.f;
+      corr[r] = 0.f;
+    }
+    const unsigned char* ap = lds + cur * W3_BUF + (wr + li) * W3_LDB + 16 * lh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nslab) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * s);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + W3_PIECE);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + 2 * W3_PIECE);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[s], corr, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[s], acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave has finished reducing the previous tile out of Cs
+    {
+      float* cw = Cs + (wr + 4 * lh) * EF_LDC + gc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * EF_LDC] = (acc[r] + corr[r]) + bv;
+    }
+    if (has1) consume_gather(B1, lds + (cur ^ 1) * W3_BUF);
+    __syncthreads();
+
+    // ---- the tile's messages: written once, reduced per destination row in k_pna_agg_fwd's operation order
+    {
+      const int cnt = count_of(B0);
+      if (ak_ok) {
+        if (g.m != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = ar + 16 * i;
+            if (r < cnt)
+              *reinterpret_cast<f32x4*>(g.m + (int64_t)(B0.e0 + r) * H + coff + ak) =
+                  *reinterpret_cast<const f32x4*>(Cs + r * EF_LDC + ak);
+          }
+        }
+        for (int k = 0;; ++k) {
+          const int node = B0.n0 + ar + 16 * k;
+          if (node >= B0.n1) break;
+          int p0, p1;
+          if (k == 0) {
+            p0 = R0[0][0];
+            p1 = R0[0][1];
+          } else if (k == 1) {
+            p0 = R0[1][0];
+            p1 = R0[1][1];
+          } else {
+            p0 = g.rowptr[node];
+            p1 = g.rowptr[node + 1];
+          }
+          const int d = p1 - p0;
+          p0 -= B0.e0;
+          p1 -= B0.e0;
+          p1 = p1 < cnt ? p1 : cnt;
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = s;
+          f32x4 mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          for (int p = p0; p < p1; ++p) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + p * EF_LDC + ak);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              s[v] = __fadd_rn(s[v], a[v]);
+              s2[v] = __fadd_rn(s2[v], __fmul_rn(a[v], a[v]));
+              mn[v] = fminf(mn[v], a[v]);
+              mx[v] = fmaxf(mx[v], a[v]);
+            }
+          }
+          const float cntf = (float)(d > 0 ? d : 1);
+          f32x4 mean, sd;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            mean[v] = __fdiv_rn(s[v], cntf);
+            const float mean2 = __fdiv_rn(s2[v], cntf);
+            const float var = __fsub_rn(mean2, __fmul_rn(mean[v], mean[v]));
+            const float o = __fsqrt_rn(fmaxf(var, STD_VAR_MIN));
+            sd[v] = (o <= STD_MASK_AT) ? 0.f : o;
+            if (d == 0) {
+              mn[v] = 0.f;
+              mx[v] = 0.f;
+            }
+          }
+          float* o = g.A + ((int64_t)node * T + tw) * (int64_t)(4 * F) + ak;
+          *reinterpret_cast<f32x4*>(o) = mean;
+          *reinterpret_cast<f32x4*>(o + F) = mn;
+          *reinterpret_cast<f32x4*>(o + 2 * F) = mx;
+          *reinterpret_cast<f32x4*>(o + 3 * F) = sd;
+        }
+      }
+    }
+    // rotate the pipeline
+    B0 = B1;
+    B1 = B2;
+    B2 = B3;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      R0[k][0] = R1[k][0];
+      R0[k][1] = R1[k][1];
+    }
+    cur ^= 1;
+    j = j1;
+  }
+}
+
+// messages h1 W1^T + b1 and their aggregate from P / Q / Te (see the header of this file).  h1 / m may be NULL (not kept:
+// inference).  W1 / b1: HOST arrays of T device pointers.  tile_info from gnx_edge_tiles(tile_w); F % 4 == 0, F <= 128.
+extern "C" int32_t gnx_pna_edge_fwd(gnx_handle* h, const float* P, const float* Q, const float* Te, const int32_t* src,
+                                    const int32_t* dst, const int32_t* code, const int32_t* rowptr,
+                                    const int32_t* tile_info, int32_t tile_w, int64_t N, int64_t E, int32_t T, int32_t F,
+                                    const float* const* W1, const float* const* b1, float* h1, float* m, float* A) {
+  GNX_CHECK_ARG(h && T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 4 && F <= 128 && F % 4 == 0 && N >= 0 && E >= 0,
+                "gnx_pna_edge_fwd: bad shape T=%d F=%d (need F %% 4 == 0, F <= 128)", T, F);
+  if (N == 0) return GNX_OK;
+  GNX_CHECK_ARG(A && rowptr && W1 && b1, "gnx_pna_edge_fwd: NULL argument");
+  if (E == 0) return gnx_fill(h, A, N * (int64_t)T * 4 * F, 0.f);  // empty rows: mean = min = max = std = 0
+  GNX_CHECK_ARG(P && Q && Te && src && dst && code && tile_info && tile_w >= 1 && tile_w <= EF_BM,
+                "gnx_pna_edge_fwd: NULL argument or bad tile width %d", tile_w);
+  edge_fwd_args g;
+  g.P = P;
+  g.Q = Q;
+  g.Te = Te;
+  g.src = src;
+  g.dst = dst;
+  g.code = code;
+  g.rowptr = rowptr;
+  g.tile_info = tile_info;
+  g.ntiles = gnx_edge_tiles_count(E, tile_w);
+  g.T = T;
+  g.F = F;
+  g.H = T * F;
+  g.N = N;
+  g.E = E;
+  for (int t = 0; t < GNX_PNA_MAX_TOWERS; ++t) {
+    g.W[t] = t < T ? W1[t] : nullptr;
+    g.b[t] = t < T ? b1[t] : nullptr;
+    GNX_CHECK_ARG(t >= T || (g.W[t] && g.b[t]), "gnx_pna_edge_fwd: W1[%d] / b1[%d] is NULL", t, t);
+  }
+  g.h1 = h1;
+  g.m = m;
+  g.A = A;
+  g.flag = h->d_flag;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_edge_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024)));
+    attr_set = true;
+  }
+  const double H = (double)T * F;
+  // own algorithmic bytes: P and Q rows once (8NH), indices + CSR (16E + 4N), A (16NH), h1 / m if kept (4EH each)
+  const double bytes = 24.0 * N * H + 16.0 * E + 4.0 * N + 4.0 * E * H * ((h1 ? 1 : 0) + (m ? 1 : 0));
+  const double flops = 2.0 * E * (double)F * F * T;
+  gnx_prof_scope prof(h, GNX_K_PNA_EDGE_FWD, bytes, flops, 6.0 * flops, true);
+  int grid = h->num_cus > 0 ? h->num_cus : 256;
+  const int64_t want = (int64_t)g.ntiles * T;
+  if (grid > want) grid = (int)want;
+  grid = grid / T * T;
+  if (grid < T) grid = T;
+  GNX_LAUNCH_TIMED(prof, k_pna_edge_fwd, dim3((unsigned)grid), dim3(512), (size_t)EF_LDS, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

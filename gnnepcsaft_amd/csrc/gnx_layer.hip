@@ -25,6 +25,8 @@ inline gnx_gemm_seg seg(const float* a, int64_t lda, const float* b, int64_t ldb
   return s;
 }
 
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 struct WgradQueue {
   std::vector<gnx_wgrad_prob> q;
   void add(const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M, int32_t N, int32_t K, float* dW,
@@ -275,15 +277,31 @@ extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
     GNX_TRY(gnx_gemm(h, 1, &sp, N, F, nullptr, nullptr, 0, a->P + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
     GNX_TRY(gnx_gemm(h, 1, &sq, N, F, nullptr, nullptr, 0, a->Q + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
   }
-  GNX_TRY(gnx_edge_combine_fwd(h, a->P, a->Q, a->Te, a->src, a->dst, a->code, E, H, pre > 1 ? 1 : 0, a->hs[0]));
-  for (int i = 1; i < pre; ++i)
-    for (int t = 0; t < T; ++t) {
-      const int k = 4 + t * per + 2 * i;
-      gnx_gemm_seg s = seg(a->hs[i - 1] + t * F, H, W[k], F, F);
-      GNX_TRY(gnx_gemm(h, 1, &s, E, F, W[k + 1], nullptr, 0, a->hs[i] + t * F, H,
-                       GNX_GEMM_B_TRANS | (i < pre - 1 ? GNX_GEMM_RELU : 0), a->ws, a->ws_bytes));
-    }
-  GNX_TRY(gnx_pna_aggregate_fwd(h, a->hs[pre - 1], a->rowptr, N, E, T, F, a->A));
+  // edge pipeline: message assembly -> pre layers 1.. -> scatter-aggregate.  With two pre layers (the reference's default)
+  // it is ONE launch (gnx_pna_edge_fwd: h1 and the messages are written once and never read back, bit-identical results)
+  bool fused = h->opt[GNX_OPT_EDGE_FUSED] != 0 && pre == 2 && a->etile_info != nullptr && E > 0 && F % 4 == 0 && F <= 128 &&
+               a16(a->P) && a16(a->Q) && a16(a->Te) && a16(a->hs[0]) && a16(a->hs[1]) && a16(a->A);
+  const float* W1[GNX_PNA_MAX_TOWERS];
+  const float* b1[GNX_PNA_MAX_TOWERS];
+  for (int t = 0; t < T && fused; ++t) {
+    W1[t] = W[4 + t * per + 2];
+    b1[t] = W[4 + t * per + 3];
+    fused = a16(W1[t]);
+  }
+  if (fused) {
+    GNX_TRY(gnx_pna_edge_fwd(h, a->P, a->Q, a->Te, a->src, a->dst, a->code, a->rowptr, a->etile_info, a->etile_w, N, E, T, F,
+                             W1, b1, a->hs[0], a->hs[1], a->A));
+  } else {
+    GNX_TRY(gnx_edge_combine_fwd(h, a->P, a->Q, a->Te, a->src, a->dst, a->code, E, H, pre > 1 ? 1 : 0, a->hs[0]));
+    for (int i = 1; i < pre; ++i)
+      for (int t = 0; t < T; ++t) {
+        const int k = 4 + t * per + 2 * i;
+        gnx_gemm_seg s = seg(a->hs[i - 1] + t * F, H, W[k], F, F);
+        GNX_TRY(gnx_gemm(h, 1, &s, E, F, W[k + 1], nullptr, 0, a->hs[i] + t * F, H,
+                         GNX_GEMM_B_TRANS | (i < pre - 1 ? GNX_GEMM_RELU : 0), a->ws, a->ws_bytes));
+      }
+    GNX_TRY(gnx_pna_aggregate_fwd(h, a->hs[pre - 1], a->rowptr, N, E, T, F, a->A));
+  }
   for (int t = 0; t < T; ++t) {
     const int k = 4 + t * per + 2 * pre;
     gnx_gemm_seg s2[2] = {seg(a->x + t * F, H, W[k], 13 * F, F), seg(a->A + (int64_t)t * 4 * F, (int64_t)T * 4 * F, a->weff[t], 4 * F, 4 * F)};

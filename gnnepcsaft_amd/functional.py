@@ -38,6 +38,15 @@ def prepare_ahead_enabled() -> bool:
 
 _BOND_CHAIN_ASIDE = True
 _NATIVE_LAYER_BWD = True
+_FUSED_EDGE = True
+
+
+def set_fused_edge(enabled: bool) -> None:
+    """A/B switch: PNAConv's edge pipeline (message assembly -> pre-layer 1 -> aggregate) as one fused kernel when the
+    layer has two pre layers and the batch's in-degree bound admits edge tiles (default on; bit-identical results)."""
+    global _FUSED_EDGE
+    _FUSED_EDGE = bool(enabled)
+
 
 
 def set_native_layer_backward(enabled: bool) -> None:
@@ -412,6 +421,10 @@ def _pna_forward_native(ctx, x, BE, pack, cfg, params, dc, prep):
     for i, t_ in enumerate(zs):
         a.zs[i] = t_.data_ptr()
     a.ws, a.ws_bytes, a.out = ws.data_ptr(), ws_bytes, out.data_ptr()
+    # edge tiles of the fused gather -> pre-layer 1 -> aggregate kernel (D - 1 bounds the in-degree: a batch above the
+    # hint trips the range flag); the library falls back to the three-launch sequence when it is not eligible
+    etiles = pack.edge_tiles(D - 1) if (_FUSED_EDGE and pre_layers == 2) else None
+    a.etile_info, a.etile_w = (etiles[0].data_ptr(), etiles[1]) if etiles is not None else (None, 0)
     ops.check(lib.gnx_pna_conv_fwd(_lib.handle(dev), C.byref(a)))
     amp, att = pack.degree_scalers(avg_deg_log)
     ctx.pack, ctx.cfg = pack, cfg[:5]

@@ -68,7 +68,26 @@ class GraphPack:
     """
 
     __slots__ = ("N", "E", "B", "rowptr", "perm", "src", "dst", "colptr", "cpos", "code", "graph_ptr", "device",
-                 "_scalers", "has_batch", "_classes", "_code_index", "max_degree_hint")
+                 "_scalers", "has_batch", "_classes", "_code_index", "max_degree_hint", "_edge_tiles")
+
+    EDGE_TILE_ROWS = 64     # message rows of one tile of the fused edge kernels (gnx_pna_edge_fwd)
+    EDGE_TILE_MAX_DEG = 16  # above this in-degree bound the tiles would be mostly padding: unfused kernels instead
+
+    def edge_tiles(self, max_degree: int) -> Optional[Tuple[torch.Tensor, int]]:
+        """(tile_info int32[2 (count + 1)], tile width) of gnx_edge_tiles for in-degrees <= ``max_degree`` (tile j = the
+        nodes whose first CSR position lies in [w j, w (j + 1)), w = 65 - max_degree, so no tile exceeds 64 message
+        rows); None when the bound is too large for the fused edge kernels or the batch has no edges.  Built once."""
+        if max_degree > GraphPack.EDGE_TILE_MAX_DEG or self.E == 0 or self.N == 0:
+            return None
+        w = GraphPack.EDGE_TILE_ROWS + 1 - max(int(max_degree), 1)
+        hit = self._edge_tiles
+        if hit is None or hit[1] != w:
+            lib = _lib.load()
+            count = lib.gnx_edge_tiles_count(self.E, w)
+            info = torch.empty(2 * (count + 1), dtype=torch.int32, device=self.device)
+            check(lib.gnx_edge_tiles(handle(self.device), self.rowptr.data_ptr(), self.N, self.E, w, info.data_ptr()))
+            hit = self._edge_tiles = (info, w)
+        return hit
 
     def code_index(self, R: int) -> Optional[torch.Tensor]:
         """CSR positions stably grouped by bond code (inverted index for the bond-table gradient); None if R > 64."""
@@ -176,6 +195,7 @@ def pack_graph(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], batc
     i32 = dict(dtype=torch.int32, device=dev)
     g = GraphPack()
     g.N, g.E, g.device, g._scalers, g._classes, g._code_index = N, E, dev, {}, None, None
+    g._edge_tiles = None
     g.max_degree_hint = None
     g.rowptr = torch.empty(N + 1, **i32)
     g.colptr = torch.empty(N + 1, **i32)
@@ -681,6 +701,32 @@ def bond_code_index(g: GraphPack, R: int, H: int) -> Optional[torch.Tensor]:
 def edge_combine_bwd(gr: torch.Tensor, g: GraphPack, R: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     dP, dQ = edge_combine_bwd_pq(gr, g)
     return dP, dQ, bond_table_grad(gr, g, R, bond_code_index(g, R, gr.size(1)))
+
+
+def pna_edge_fwd(P: torch.Tensor, Q: torch.Tensor, Te: torch.Tensor, g: GraphPack, T: int, F: int,
+                 weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], max_degree: int,
+                 keep: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], torch.Tensor]:
+    """Fused message assembly -> pre-layer 1 -> aggregate (gnx_pna_edge_fwd): returns (h1 [E,H], m [E,H], A [N,T*4F]);
+    ``keep=False`` does not materialise h1 / m (inference).  ``weights`` / ``biases``: pre-layer 1 of every tower."""
+    H = T * F
+    tiles = g.edge_tiles(max_degree)
+    if tiles is None and g.E > 0:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"pna_edge_fwd: in-degree bound {max_degree} too large for edge tiles")
+    dev = P.device
+    h1 = torch.empty(g.E, H, dtype=torch.float32, device=dev) if keep else None
+    m = torch.empty(g.E, H, dtype=torch.float32, device=dev) if keep else None
+    A = torch.empty(g.N, T * 4 * F, dtype=torch.float32, device=dev)
+    warr = (C.c_void_p * T)(*[_f32(w, "W1").data_ptr() for w in weights])
+    barr = (C.c_void_p * T)(*[_f32(b, "b1").data_ptr() for b in biases])
+    for w in weights:
+        if tuple(w.shape) != (F, F) or not w.is_contiguous():
+            raise _lib.GnxError(_lib.GNX_E_INVALID, f"pna_edge_fwd: pre-layer 1 weight must be contiguous [{F},{F}]")
+    info, w_ = tiles if tiles is not None else (None, 1)
+    check(_lib.load().gnx_pna_edge_fwd(handle(dev), P.data_ptr(), Q.data_ptr(), Te.data_ptr(), g.src.data_ptr(),
+                                       g.dst.data_ptr(), g.code.data_ptr(), g.rowptr.data_ptr(), _ptr(info), w_, g.N, g.E,
+                                       T, F, C.cast(warr, C.POINTER(C.c_void_p)), C.cast(barr, C.POINTER(C.c_void_p)),
+                                       _ptr(h1), _ptr(m), A.data_ptr()))
+    return h1, m, A
 
 
 def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNX_ABI_VERSION 2
+#define GNX_ABI_VERSION 3
 
 enum {
   GNX_OK = 0,
@@ -61,7 +61,8 @@ enum {
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
   GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
-  GNX_OPT_COUNT = 10
+  GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd takes the fused gather -> pre-layer 1 -> aggregate kernel when eligible (bit-identical results) */
+  GNX_OPT_COUNT = 11
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
@@ -85,7 +86,8 @@ enum {
   GNX_K_GEMM_WGRAD_BATCHED = 13,/* a layer's weight gradients in one launch */
   GNX_K_KEY_SEGMENT_SUM = 14,   /* bond-table gradient through the inverted index */
   GNX_K_EMBED = 15,             /* embedding sums, forward and backward */
-  GNX_K_COUNT = 16
+  GNX_K_PNA_EDGE_FWD = 16,      /* fused message assembly -> pre-layer 1 -> scatter-aggregate (gnx_pna_edge_fwd) */
+  GNX_K_COUNT = 17
 };
 /* start recording a HIP event pair around every launch of the kernels whose id bit is set in kernel_mask
  * (bit k = GNX_K_* id k).  Events go on the handle's stream, i.e. the stream the kernels run on. */
@@ -267,6 +269,24 @@ int32_t gnx_pna_aggregate_fwd(gnx_handle* h, const float* m, const int32_t* rowp
 int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, const float* A, const int32_t* rowptr,
                               int64_t N, int64_t E, int32_t T, int32_t F, float* dm);
 
+/* ---- fused PNA edge pipeline: message assembly -> pre-layer 1 -> scatter-aggregate in one kernel ---------------- */
+/* [3P] PNAConv.message + DegreeScalerAggregation for pre_layers = 2 (ref: train/models.py:445-457, configs/default.py:44):
+ *   h1[p] = relu(P[dst[p]] + Q[src[p]] + Te[code[p]]);  m[p] = h1[p] W1_t^T + b1_t per tower;  A[n] = mean|min|max|std of
+ *   the CSR row of n -- the work of gnx_edge_combine_fwd + gnx_gemm + gnx_pna_aggregate_fwd without reading h1 or m back
+ *   from HBM; h1, m and A come out bit-identical to that sequence.  h1 / m (fp32[E, T*F]) may be NULL (not kept).
+ * Edge tiles: gnx_edge_tiles groups the destination nodes so that tile j = the nodes whose first CSR position lies in
+ *   [tile_w j, tile_w (j+1)); tile_info int32[2 (count + 1)] = (first node, first CSR position) per tile, count =
+ *   gnx_edge_tiles_count(E, tile_w).  With in-degrees <= maxdeg, tile_w = 65 - maxdeg keeps every tile within the kernel's
+ *   64 message rows; a tile that exceeds them (a degree above the bound) drops rows and sets sticky range-flag bit 6
+ *   (gnx_check_range).  W1 / b1: HOST arrays of T device pointers ([F,F] row-major [out,in], [F]).  F % 4 == 0, F <= 128,
+ *   float operands 16-byte aligned. */
+int32_t gnx_edge_tiles_count(int64_t E, int32_t tile_w);
+int32_t gnx_edge_tiles(gnx_handle* h, const int32_t* rowptr, int64_t N, int64_t E, int32_t tile_w, int32_t* tile_info);
+int32_t gnx_pna_edge_fwd(gnx_handle* h, const float* P, const float* Q, const float* Te, const int32_t* src,
+                         const int32_t* dst, const int32_t* code, const int32_t* rowptr, const int32_t* tile_info,
+                         int32_t tile_w, int64_t N, int64_t E, int32_t T, int32_t F, const float* const* W1,
+                         const float* const* b1, float* h1, float* m, float* A);
+
 /* ---- GINE message + sum aggregate (fused gather, no materialised messages) --------------------------------- */
 /* [3P] GINEConv (ref: train/models.py:529-538): out[i,:] = (1+eps) x[i,:] + sum_{p in row i} relu(x[src[p],:] + Le[code[p],:]) */
 int32_t gnx_gine_aggregate_fwd(gnx_handle* h, const float* x, const float* Le, const int32_t* rowptr,
@@ -397,6 +417,9 @@ typedef struct {
   void* ws;                                    /* >= gnx_pna_conv_bwd_workspace_bytes(T, F, D) */
   size_t ws_bytes;
   float* out;                                  /* [N,H] */
+  const int32_t* etile_info;                   /* gnx_edge_tiles table (NULL: unfused edge pipeline) */
+  int32_t etile_w;                             /* its tile width */
+  int32_t _pad;
 } gnx_pna_fwd_args;
 int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* args);
 

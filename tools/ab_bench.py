@@ -36,11 +36,12 @@ VARIANTS = {
     "rows1024": lambda dev: setattr(ops.DegreeClasses, "WGRAD_ROWS", 1024),
     "rows2048": lambda dev: setattr(ops.DegreeClasses, "WGRAD_ROWS", 2048),
     "nobatch": lambda dev: ops.set_wgrad_batching(False),
+    "nofused": lambda dev: Fn.set_fused_edge(False),
 }
 
 
 def reset(dev):
-    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True)
+    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True); Fn.set_fused_edge(True)
     ops.set_option(dev, _lib.OPT_STD_BWD_CENTERED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1)
     ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
