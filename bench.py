@@ -16,10 +16,13 @@ equal the number of ranks, N devices must be visible, and ``n_gpus`` in the JSON
 timing barrier.  ``--dry-run`` rehearses the launch / barrier / exchange protocol on the CPU (gloo, no kernels).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
-  roofline     — the scatter-aggregate kernel (gnx_pna_aggregate_fwd): algorithmic bytes per launch / its average
-                 duration, timed live with HIP events attached to the kernel's dispatch on the launch stream
-                 (hipExtLaunchKernelGGL start / stop events: the kernel's own execution time, the quantity rocprofv3's
-                 kernel trace reports) during the instrumented steps, vs 8 TB/s HBM;
+  roofline     — the scatter-aggregate: algorithmic bytes per launch (4EH + 4E + 16NH) / the average
+                 duration of the kernel that performs it in the step, timed live with HIP events attached to the kernel's
+                 dispatch on the launch stream (hipExtLaunchKernelGGL start / stop events: the kernel's own execution
+                 time, the quantity rocprofv3's kernel trace reports) during the instrumented steps, vs 8 TB/s HBM.  Since
+                 round 3 that kernel is the FUSED edge kernel (gnx_pna_edge_fwd: gather + pre-layer-1 product + aggregate);
+                 ``roofline.fused`` adds its own algorithmic bytes, ``roofline.standalone_scatter_kernel`` the stand-alone
+                 gnx_pna_aggregate_fwd on the same CSR;
   cpu_baseline — the oracle (pure-torch restatement of the reference's PyG CPU path, kind "port") timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -362,6 +365,10 @@ def main():
     prof_iso = instrumented(False) if not args.no_side_stream else prof_run
     ops.set_wgrad_side_stream(not args.no_side_stream)
     large = scatter_past_l3(dev, cfg) if (rank == 0 and cfg["conv"] == "PNA") else None
+    # the step's PNA layers run the scatter-aggregate inside the fused edge kernel (gnx_pna_edge_fwd) when eligible; the
+    # stand-alone kernel (gnx_pna_aggregate_fwd: hub-heavy batches, pre_layers != 2) is then timed on this batch's CSR
+    fused_fwd = cfg["conv"] == "PNA" and prof_run[_lib.K_PNA_EDGE_FWD]["launches"] > 0
+    standalone = scatter_standalone(dev, cfg, b, model) if (rank == 0 and fused_fwd) else None
     joined = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -385,17 +392,35 @@ def main():
                     "gbs": (p[k]["bytes"] / (p[k]["ms"] * 1e-3) / 1e9) if p[k]["ms"] > 0 else 0.0}
 
         f_run, f_iso = per_launch(prof_run, agg_k), per_launch(prof_iso, agg_k)
+        roof_kernel = "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd"
+        fused_info = None
+        if fused_fwd:
+            # a fused gather -> MLP -> aggregate kernel is reported against the SAME algorithmic figure as
+            # the scatter-aggregate alone (4EH + 4E + 16NH per launch) and, additionally, against its own bytes
+            fr, fi = per_launch(prof_run, _lib.K_PNA_EDGE_FWD), per_launch(prof_iso, _lib.K_PNA_EDGE_FWD)
+            scatter_bytes = 4.0 * E_edges * H + 4.0 * E_edges + 16.0 * N_nodes * H
+            fused_info = {"own_alg_bytes_per_launch": fr["bytes"], "own_achieved": fr["gbs"],
+                          "own_frac": fr["gbs"] / HBM_PEAK_GBS,
+                          "what": "message assembly (gather of P, Q, Te rows) + pre-layer-1 split-bf16 product + "
+                                  "mean|min|max|std in one launch; writes h1, the messages and the aggregate once"}
+            for d_ in (fr, fi):
+                d_["bytes"] = scatter_bytes
+                d_["gbs"] = scatter_bytes / (d_["avg_us"] * 1e-6) / 1e9 if d_["avg_us"] > 0 else 0.0
+            f_run, f_iso = fr, fi
+            roof_kernel = "k_pna_edge_fwd (fused: scatter-aggregate inside the edge kernel)"
         b_run, b_iso = per_launch(prof_run, agg_bk), per_launch(prof_iso, agg_bk)
         # HBM traffic of the scatter kernel from the PMC counters: only if the committed counter file was collected on
         # THIS workload (same conv, atoms, bonds, width); otherwise null
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_scatter.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 if (pj.get("conv", "PNA") == cfg["conv"] and pj.get("N") == N_nodes and pj.get("E") == E_edges
-                        and pj.get("H") == H):
+                        and pj.get("H") == H and pj.get("kernel", "k_pna_agg_fwd").startswith(roof_kernel.split(" ")[0])):
                     traffic = pj.get("traffic_bytes_per_launch")
+                    # PMC counters need rocprofv3: the figure is NOT measured in this run, it is read from the committed file
+                    traffic_src = f"profiles/pmc_scatter.json ({pj.get('round', 'r?')}, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             except Exception:  # pylint: disable=broad-except
                 traffic = None
         # the step's products: algorithmic FLOPs executed (the restructured layers do fewer than the reference
@@ -438,9 +463,10 @@ def main():
             # the scatter-aggregate kernel: algorithmic bytes per launch / average launch duration (HIP events attached
             # to the dispatch on the launch stream, as run); "bwd" carries both the as-run (two streams) and the isolated duration; "large"
             # is the same forward kernel on cfg-4's per-GPU batch, whose 1.0 GB per launch does not fit the Infinity Cache
-            "roofline": {"bound": "hbm", "kernel": "k_pna_agg_fwd" if cfg["conv"] == "PNA" else "k_gine_fwd",
+            "roofline": {"bound": "hbm", "kernel": roof_kernel, "fused": fused_info, "standalone_scatter_kernel": standalone,
                          "achieved": f_run["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_run["gbs"] / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": f_run["bytes"], "avg_us": f_run["avg_us"],
+                         "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": f_run["bytes"],
+                         "avg_us": f_run["avg_us"],
                          "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL start/stop)",
                          "launches": f_run["launches"], "avg_us_isolated": f_iso["avg_us"],
                          "bwd": {"alg_bytes_per_launch": b_run["bytes"], "avg_us": b_run["avg_us"], "achieved": b_run["gbs"],
@@ -466,6 +492,28 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scatter_standalone(dev, cfg, b, model, launches: int = 12):
+    """The stand-alone scatter-aggregate kernel (gnx_pna_aggregate_fwd) on the bench batch's own CSR with random
+    messages, timed with the same dispatch-attached events: what the kernel does when a layer is not eligible for the
+    fused edge kernel (and the figure earlier rounds reported as ``roofline``)."""
+    from gnnepcsaft_amd import _lib, ops
+    from gnnepcsaft_amd.train.models import _pack_of
+    H, T = cfg["hidden_dim"], cfg["towers"]
+    pack = _pack_of(b, False, model.model.max_degree_hint)
+    m = torch.randn(pack.E, H, device=dev)
+    for _ in range(2):
+        ops.pna_aggregate_fwd(m, pack, T, H // T)
+    ops.prof_begin(dev, [_lib.K_PNA_AGG_FWD])
+    for _ in range(launches):
+        ops.pna_aggregate_fwd(m, pack, T, H // T)
+    r = ops.prof_read_work(dev, _lib.K_PNA_AGG_FWD)
+    ops.prof_end(dev)
+    n = max(r["launches"], 1)
+    gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
+    return {"kernel": "k_pna_agg_fwd", "launches": r["launches"], "alg_bytes_per_launch": r["bytes"] / n,
+            "avg_us": r["ms"] / n * 1e3, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
 
 
 def scatter_past_l3(dev, cfg, launches: int = 12):

@@ -30,7 +30,9 @@
 #define EF_LDC 132                            // floats per row of the fp32 message tile (33 x 16 B: odd)
 #define EF_A_BYTES (2 * W3_BUF)               // two stages of three bf16 images [64][128 (+8)]
 #define EF_C_BYTES (EF_BM * EF_LDC * 4)
-#define EF_LDS (EF_A_BYTES + EF_C_BYTES)      // 138 240 B: one workgroup per CU
+#define EF_RP 128                             // CSR bounds of a tile's first 128 nodes are staged in LDS (two stages)
+#define EF_RP_BYTES (2 * (EF_RP + 4) * 4)
+#define EF_LDS (EF_A_BYTES + EF_C_BYTES + EF_RP_BYTES)  // 139 296 B: one workgroup per CU
 
 struct edge_fwd_args {
   const float* P;
@@ -49,7 +51,24 @@ struct edge_fwd_args {
   float* m;   // [E, H] or NULL
   float* A;   // [N, T, 4F]
   int* flag;
+#ifdef EF_STAMP
+  unsigned long long* stamps;  // diagnostic build only (tools/ubench/edge_fwd_stamp.hip): 8 phase sums per workgroup
+#endif
 };
+
+// phase stamps of the diagnostic build: cycles since the previous stamp are added to phase `i` (thread 0 stores the sums)
+#ifdef EF_STAMP
+#define EF_AT(i)                                     \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    const unsigned long long tn_ = clock64();        \
+    tacc[i] += tn_ - tprev;                          \
+    tprev = tn_;                                     \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#else
+#define EF_AT(i)
+#endif
 
 __global__ void k_edge_tiles(const int* __restrict__ rowptr, int64_t N, int64_t E, int W, int ntiles,
                              int* __restrict__ info) {
@@ -84,9 +103,14 @@ extern "C" int32_t gnx_edge_tiles(gnx_handle* h, const int32_t* rowptr, int64_t 
   return GNX_OK;
 }
 
+#ifdef EF_STAMP
+static unsigned long long* ef_stamp_buf = nullptr;
+#endif
+
 __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* Cs = reinterpret_cast<float*>(lds + EF_A_BYTES);
+  int* rpl = reinterpret_cast<int*>(lds + EF_A_BYTES + EF_C_BYTES);  // [2][EF_RP + 4]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
@@ -109,10 +133,23 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
   struct bounds {
     int n0, e0, n1, e1;
   };
-  auto load_bounds = [&](int j) {
-    const int jj = j < last ? j : last;  // clamped: tiles past the end are never processed, their loads stay in range
+  // Tile bounds come out of a lane vector, not out of memory: lane l holds (n0, e0, n1, e1) of the workgroup's l-th tile
+  // counted from `vbase` (refilled every 32 tiles), and v_readlane hands tile i's bounds to the scalar unit.  A uniform
+  // global load here compiles to a VECTOR load + readfirstlane behind s_waitcnt vmcnt(0), i.e. every iteration would wait
+  // for the gather it has just issued and for the previous tile's stores.
+  int vb_n0, vb_e0, vb_n1, vb_e1;
+  auto fill_bounds = [&](int jbase) {
+    const int jt = jbase + lane * tstride;
+    const int jj = jt < last ? jt : last;  // clamped: tiles past the end are never processed, their loads stay in range
     const int2 a = tinfo[jj], c = tinfo[jj + 1];
-    bounds b = {a.x, a.y, c.x, c.y};
+    vb_n0 = a.x;
+    vb_e0 = a.y;
+    vb_n1 = c.x;
+    vb_e1 = c.y;
+  };
+  auto bounds_at = [&](int rel) {  // rel: wave-uniform, < 64
+    bounds b = {__builtin_amdgcn_readlane(vb_n0, rel), __builtin_amdgcn_readlane(vb_e0, rel),
+                __builtin_amdgcn_readlane(vb_n1, rel), __builtin_amdgcn_readlane(vb_e1, rel)};
     return b;
   };
   auto count_of = [&](const bounds& b) {
@@ -120,19 +157,20 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
     return c < EF_BM ? c : EF_BM;
   };
 
-  int idx[4][3];  // dst, src, code of rows ar + 16 i of the tile whose gather is issued next
-  auto load_idx = [&](const bounds& b) {
+  // dst, src, code of rows ar + 16 i of a tile
+  auto load_idx = [&](const bounds& b, int (&ix)[4][3]) {
     const int cm1 = count_of(b) - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = ar + 16 * i;
       int e = b.e0 + (r < cm1 ? r : (cm1 > 0 ? cm1 : 0));
       e = e < Em1 ? e : Em1;
-      idx[i][0] = g.dst[e];
-      idx[i][1] = g.src[e];
-      idx[i][2] = g.code[e];
+      ix[i][0] = g.dst[e];
+      ix[i][1] = g.src[e];
+      ix[i][2] = g.code[e];
     }
   };
+  int idx[4][3];  // ... of the tile whose gather is issued next
   f32x4 ga[4][3];
   auto issue_gather = [&]() {
 #pragma unroll
@@ -142,14 +180,11 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
       ga[i][2] = *reinterpret_cast<const f32x4*>(g.Te + (int64_t)idx[i][2] * H + coff + akc);
     }
   };
-  // CSR bounds of the first two nodes this thread aggregates
-  auto load_rp = [&](const bounds& b, int (&r)[2][2]) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int64_t node = (int64_t)b.n0 + ar + 16 * k;
-      r[k][0] = g.rowptr[node < g.N ? node : g.N];
-      r[k][1] = g.rowptr[node + 1 < g.N ? node + 1 : g.N];
-    }
+  // CSR bounds of the tile's nodes: rowptr[n0 .. n0 + EF_RP] go through LDS (thread t < EF_RP + 1 carries entry t), so that
+  // the reduction below waits on no vector-memory counter
+  auto load_rp = [&](const bounds& b) {
+    const int64_t node = (int64_t)b.n0 + (tid <= EF_RP ? tid : EF_RP);
+    return g.rowptr[node < g.N ? node : g.N];
   };
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   // gathered rows -> h1 (k_edge_combine_fwd's expression) -> global h1 + three bf16 images of LDS stage `buf`
@@ -188,11 +223,12 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
 
   const float bv = (gc < F) ? g.b[tw][gc] : 0.f;
   int j = blockIdx.x / T;  // grid <= ntiles * T
-  bounds B0 = load_bounds(j), B1 = load_bounds(j + tstride), B2 = load_bounds(j + 2 * tstride);
-  load_idx(B0);
+  fill_bounds(j);
+  int rel = 0;  // position of tile j in the lane vector
+  bounds B0 = bounds_at(0), B1 = bounds_at(1), B2 = bounds_at(2);
+  load_idx(B0, idx);
   issue_gather();  // in flight while the weight fragments are fetched and split
-  int R0[2][2];
-  load_rp(B0, R0);
+  if (tid <= EF_RP) rpl[tid] = load_rp(B0);
 
   // ---- this wave's pre-layer-1 weight fragments, split once: lane holds column gc, k = 16 s + 8 lh + jj
   bf16x8 b1[8], b2[8], b3[8];
@@ -217,21 +253,29 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
     }
   }
   consume_gather(B0, lds);
-  load_idx(B1);
+  load_idx(B1, idx);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(idx[i][0]), "v"(idx[i][1]), "v"(idx[i][2]));  // arrived before the loop
   __syncthreads();
 
   int cur = 0;
+#ifdef EF_STAMP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = clock64();
+#endif
   while (j < g.ntiles) {
     const int j1 = j + tstride;
     const bool has1 = j1 < g.ntiles;
-    int R1[2][2] = {{0, 0}, {0, 0}};
-    if (has1) {  // wave-uniform; the gather of tile j1 stays in flight under the MFMAs below
-      issue_gather();
-      load_rp(B1, R1);
-    }
-    load_idx(B2);  // tile j + 2 (clamped bounds past the end: harmless loads)
-    const bounds B3 = load_bounds(j1 + 2 * tstride);
+    // loads of the next tiles, oldest first: CSR bounds of tile j1, indices of tile j + 2, then the gather of tile j1 (it
+    // stays in flight under the MFMAs; the two small loads ahead of it are touched right after them)
+    const int rpv = load_rp(B1);
+    int idn[4][3];
+    load_idx(B2, idn);  // (clamped bounds past the end: harmless loads)
+    __builtin_amdgcn_sched_barrier(0);  // keep the small loads AHEAD of the gather in the vmcnt queue
+    issue_gather();  // unconditional (past the end: clamped, harmless loads) so that hipcc can COUNT the loads behind idn
+    const bounds B3 = bounds_at(rel + 3);
     if (tid == 0 && B0.e1 - B0.e0 > EF_BM) atomicOr(g.flag, 64);
+    EF_AT(0);  // issue of the next tile's loads
 
     f32x16 acc, corr;
 #pragma unroll
@@ -254,14 +298,26 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[s], acc, 0, 0, 0);
       }
     }
+    EF_AT(1);  // fragment reads + MFMAs
+    // gfx950 counts loads AND stores in one in-order vmcnt: a load result first touched behind the tile's (data-dependent
+    // number of) stores makes hipcc wait vmcnt(0), i.e. for every store of the tile to be acknowledged (measured: 35 % of
+    // the kernel's time).  Everything loaded at the top is touched HERE, where only the gather is outstanding behind it.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(idn[i][0]), "v"(idn[i][1]), "v"(idn[i][2]));
+    asm volatile("" ::"v"(rpv));
     __syncthreads();  // every wave has finished reducing the previous tile out of Cs
+    EF_AT(2);
     {
       float* cw = Cs + (wr + 4 * lh) * EF_LDC + gc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * EF_LDC] = (acc[r] + corr[r]) + bv;
     }
+    if (tid <= EF_RP) rpl[(cur ^ 1) * (EF_RP + 4) + tid] = rpv;
+    EF_AT(3);  // result tile -> LDS
     if (has1) consume_gather(B1, lds + (cur ^ 1) * W3_BUF);
+    EF_AT(4);  // wait for the gather, h1, split, LDS stores
     __syncthreads();
+    EF_AT(5);
 
     // ---- the tile's messages: written once, reduced per destination row in k_pna_agg_fwd's operation order
     {
@@ -276,27 +332,29 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
                   *reinterpret_cast<const f32x4*>(Cs + r * EF_LDC + ak);
           }
         }
-        for (int k = 0;; ++k) {
-          const int node = B0.n0 + ar + 16 * k;
-          if (node >= B0.n1) break;
-          int p0, p1;
-          if (k == 0) {
-            p0 = R0[0][0];
-            p1 = R0[0][1];
-          } else if (k == 1) {
-            p0 = R0[1][0];
-            p1 = R0[1][1];
-          } else {
-            p0 = g.rowptr[node];
-            p1 = g.rowptr[node + 1];
-          }
+        // one destination row: reduce message rows [p0, p1) (CSR positions) out of the LDS tile
+        auto reduce_node = [&](int node, int p0, int p1) {
           const int d = p1 - p0;
           p0 -= B0.e0;
           p1 -= B0.e0;
           p1 = p1 < cnt ? p1 : cnt;
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = s;
           f32x4 mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-          for (int p = p0; p < p1; ++p) {
+          int p = p0;
+#ifndef EF_NO_AGG_UNROLL
+          for (; p + 1 < p1; p += 2) {  // two rows in flight (same operation order as one by one)
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + p * EF_LDC + ak);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + (p + 1) * EF_LDC + ak);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              s[v] = __fadd_rn(__fadd_rn(s[v], a[v]), b[v]);
+              s2[v] = __fadd_rn(__fadd_rn(s2[v], __fmul_rn(a[v], a[v])), __fmul_rn(b[v], b[v]));
+              mn[v] = fminf(mn[v], fminf(a[v], b[v]));
+              mx[v] = fmaxf(mx[v], fmaxf(a[v], b[v]));
+            }
+          }
+#endif
+          for (; p < p1; ++p) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + p * EF_LDC + ak);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -325,21 +383,38 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
           *reinterpret_cast<f32x4*>(o + F) = mn;
           *reinterpret_cast<f32x4*>(o + 2 * F) = mx;
           *reinterpret_cast<f32x4*>(o + 3 * F) = sd;
-        }
+        };
+        const int* rpc = rpl + cur * (EF_RP + 4);
+        const int nn = B0.n1 - B0.n0;  // nodes of the tile (> EF_RP only with long runs of edge-less nodes)
+        const int nl = nn < EF_RP ? nn : EF_RP;
+        for (int ln = ar; ln < nl; ln += 16) reduce_node(B0.n0 + ln, rpc[ln], rpc[ln + 1]);  // no vector-memory wait here
+        if (nn > EF_RP)  // wave-uniform, rare: the remaining nodes read their CSR bounds from global memory
+          for (int ln = EF_RP + ar; ln < nn; ln += 16) reduce_node(B0.n0 + ln, g.rowptr[B0.n0 + ln], g.rowptr[B0.n0 + ln + 1]);
       }
     }
+    EF_AT(6);  // message stores + aggregate
     // rotate the pipeline
     B0 = B1;
     B1 = B2;
     B2 = B3;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      R0[k][0] = R1[k][0];
-      R0[k][1] = R1[k][1];
+    for (int i = 0; i < 4; ++i) {
+      idx[i][0] = idn[i][0];
+      idx[i][1] = idn[i][1];
+      idx[i][2] = idn[i][2];
     }
     cur ^= 1;
     j = j1;
+    if (++rel == 32) {  // refill the bounds vector from the tile that is now current (one full wait per 32 tiles)
+      fill_bounds(j);
+      asm volatile("" ::"v"(vb_n0), "v"(vb_e0), "v"(vb_n1), "v"(vb_e1));  // waited for here, not at the loop head
+      rel = 0;
+    }
   }
+#ifdef EF_STAMP
+  if (tid == 0 && g.stamps != nullptr)
+    for (int i = 0; i < 8; ++i) g.stamps[blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 // messages h1 W1^T + b1 and their aggregate from P / Q / Te (see the header of this file).  h1 / m may be NULL (not kept:
@@ -379,6 +454,9 @@ extern "C" int32_t gnx_pna_edge_fwd(gnx_handle* h, const float* P, const float* 
   g.m = m;
   g.A = A;
   g.flag = h->d_flag;
+#ifdef EF_STAMP
+  g.stamps = ef_stamp_buf;
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_edge_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,

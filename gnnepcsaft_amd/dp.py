@@ -139,6 +139,9 @@ class FlatGradAllReduce:
         for w in self._works:
             w.wait()
         self._works = []
+        # the slice bookkeeping belongs to ONE exchange: a second backward + all_reduce without zero_grad() (gradient
+        # accumulation, or a caller that zeroes .grad itself) must exchange every slice again
+        self._done = []
         if self.world > 1:
             ops.scale_(self.flat, 1.0 / self.world)
 

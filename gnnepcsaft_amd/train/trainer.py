@@ -21,19 +21,45 @@ from ..optim import configure_fused_optimizers
 
 class DataLoader:
     """Batches a list of ``Data`` with ``Batch.from_data_list`` (PyG DataLoader semantics: optional shuffle per epoch,
-    last batch kept)."""
+    last batch kept).
 
-    def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False, seed: int = 0, **_ignored):
+    Data parallelism: with ``torch.distributed`` initialised and world size W > 1 (or explicit ``rank`` / ``world``) every
+    rank draws the SAME epoch order (same seed on every rank) and takes its strided share ``order[rank::W]`` of it, the
+    order being padded by wrapping to a multiple of W -- what Lightning injects into the reference's loaders under DDP
+    (``torch.utils.data.DistributedSampler``; /root/reference/gnnepcsaft/train/train.py:85-88): ranks see disjoint
+    graphs, every rank iterates the same number of batches, and the effective batch is W x ``batch_size``."""
+
+    def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False, seed: int = 0,
+                 rank: Optional[int] = None, world: Optional[int] = None, **_ignored):
         self.dataset, self.batch_size, self.shuffle = list(dataset), int(batch_size), bool(shuffle)
         self._rng = np.random.Generator(np.random.PCG64(seed))
+        if (rank is None) != (world is None):
+            raise ValueError("DataLoader: pass rank and world together (or neither: taken from torch.distributed)")
+        self._rank, self._world = rank, world
+
+    def _shard(self):
+        if self._world is not None:
+            return int(self._rank), int(self._world)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _per_rank(self) -> int:
+        _, world = self._shard()
+        return (len(self.dataset) + world - 1) // world
 
     def __len__(self) -> int:
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        return (self._per_rank() + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         order = np.arange(len(self.dataset))
         if self.shuffle:
             self._rng.shuffle(order)
+        rank, world = self._shard()
+        if world > 1 and len(order):
+            total = self._per_rank() * world
+            order = np.resize(order, total)[rank::world]  # np.resize pads by repeating the order from its start
         self.last_order = order
         for i in range(0, len(order), self.batch_size):
             yield Batch.from_data_list([self.dataset[j] for j in order[i:i + self.batch_size]])
@@ -184,6 +210,9 @@ class Trainer:
                 st = loops.get("loader_rng_at_epoch_start") if skip > 0 else loops.get("loader_rng_now")
                 if st is not None:
                     train_dataloaders.set_rng_state(st)
+            # a checkpoint written again before any further step (e.g. global_step >= max_steps) must keep the position
+            self._batch_in_epoch = skip
+            self._epoch_rng = loops.get("loader_rng_at_epoch_start") if skip > 0 else None
             drop = getattr(model.model, "dropout", None)
             if ckpt.get("dropout") and drop is not None and hasattr(drop, "calls"):
                 drop.seed, drop.calls = int(ckpt["dropout"]["seed"]), int(ckpt["dropout"]["calls"])
@@ -232,7 +261,11 @@ class Trainer:
                         break  # one epoch when no step budget is given
                     continue
                 # stopped inside an epoch by max_steps
-                if self._batch_in_epoch >= len(train_dataloaders):  # ... exactly at its last batch: the epoch is complete
+                try:
+                    n_batches = len(train_dataloaders)
+                except TypeError:  # an iterable without __len__: the epoch's end is only known once it is exhausted
+                    n_batches = None
+                if n_batches is not None and self._batch_in_epoch >= n_batches:  # exactly at its last batch: the epoch is complete
                     self._batch_in_epoch = 0
                     self._epoch_rng = None
                     self.current_epoch += 1

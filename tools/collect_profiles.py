@@ -1,7 +1,7 @@
 """Copies the judged summaries of a profiling run (tools/profile_round.sh) from gpurun_out/<tag>/ (scratch) into
 profiles/ (tracked).
 
-usage: python tools/collect_profiles.py [tag]        (default r02; reads gpurun_out/<tag>/)
+usage: python tools/collect_profiles.py [tag]        (default r03; reads gpurun_out/<tag>/)
 """
 import collections
 import csv
@@ -22,7 +22,7 @@ def kernel_stats(src_dir, dst):
     return False
 
 
-def main(tag="r02"):
+def main(tag="r03"):
     src = os.path.join(ROOT, "gpurun_out", tag)
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(prof, f"bench_{tag}.json"))
@@ -74,7 +74,11 @@ def main(tag="r02"):
             w.writerow(["kernel", "dispatches", "SQ_VALU_MFMA_BUSY_CYCLES_avg", "GRBM_GUI_ACTIVE_avg", "duration_us_avg",
                         "clock_GHz(GUI_ACTIVE/8/duration)", "mfma_utilisation(BUSY/(1024*GUI_ACTIVE/8))"])
             for k, n, ba, ga, us, ghz, util in sorted(rows, key=lambda r: -r[2] * r[1]):
-                w.writerow([k[:90], n, f"{ba:.0f}", f"{ga:.0f}", f"{us:.1f}", f"{ghz:.2f}", f"{util:.3f}"])
+                # GRBM_GUI_ACTIVE also counts the idle cycles around a dispatch: for kernels shorter than ~50 us the
+                # derived clock reads 2.8-4.7 GHz, so neither it nor the utilisation is reported
+                short = us < 50.0
+                w.writerow([k[:90], n, f"{ba:.0f}", f"{ga:.0f}", f"{us:.1f}", "n/a (< 50 us)" if short else f"{ghz:.2f}",
+                            "n/a (< 50 us)" if short else f"{util:.3f}"])
     if agg:
         with open(os.path.join(prof, f"{tag}_pmc_fetch_write_per_kernel.csv"), "w", newline="") as fh:
             w = csv.writer(fh)
@@ -84,14 +88,23 @@ def main(tag="r02"):
                 fa = sum(fs_) / max(len(fs_), 1)
                 wa = sum(ws_) / max(len(ws_), 1)
                 w.writerow([k[:90], max(len(fs_), len(ws_)), f"{fa:.1f}", f"{wa:.1f}", f"{(2 * fa + wa) * 1024:.0f}"])
-        key = [k for k in agg if k.startswith("void k_pna_agg_fwd") and not k.endswith("batch]")]
+        # the kernel that performs the scatter-aggregate inside the step: the fused edge kernel when it ran, else k_pna_agg_fwd
+        key = [k for k in agg if k.startswith("k_pna_edge_fwd")] or \
+              [k for k in agg if k.startswith("void k_pna_agg_fwd") and not k.endswith("batch]")]
         if key:
             fs_, ws_ = agg[key[0]]["FETCH_SIZE"], agg[key[0]]["WRITE_SIZE"]
             fa, wa = sum(fs_) / len(fs_), sum(ws_) / len(ws_)
-            old = json.load(open(os.path.join(prof, "pmc_scatter.json")))
-            old.update({"FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
-                        "conv": "PNA", "N": 81920, "E": 163840, "H": 128, "round": tag,
-                        "workload": f"bench.py cfg-2 (N=81920, E=163840, H=128), {len(fs_)} dispatches per counter pass"})
+            fused = key[0].startswith("k_pna_edge_fwd")
+            N, E, H = 81920, 163840, 128
+            old = {"kernel": "k_pna_edge_fwd" if fused else "k_pna_agg_fwd<4>",
+                   "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
+                   "algorithmic_bytes_per_launch": 4 * E * H + 4 * E + 16 * N * H,
+                   "own_algorithmic_bytes_per_launch": (24 * N * H + 16 * E + 4 * N + 8 * E * H) if fused else None,
+                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; counters "
+                             "are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide "
+                             "coalesced streaming reads); WRITE_SIZE exact for 16-B/lane stores",
+                   "conv": "PNA", "N": N, "E": E, "H": H, "round": tag,
+                   "workload": f"bench.py cfg-2 (N={N}, E={E}, H={H}), {len(fs_)} dispatches per counter pass"}
             json.dump(old, open(os.path.join(prof, "pmc_scatter.json"), "w"), indent=1)
             print("scatter traffic/launch", (2 * fa + wa) * 1024, "algorithmic", old["algorithmic_bytes_per_launch"])
 
