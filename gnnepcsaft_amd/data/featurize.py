@@ -224,9 +224,14 @@ def _implicit_hs(atoms: List[_Atom], bonds: List[_Bond]) -> None:
             ev = len(a.nbrs) + 1 if any(bonds[b].aromatic for b in a.nbrs) else ev
             ev += sum(bonds[b].order - 1 for b in a.nbrs if not bonds[b].aromatic)
         ev = int(round(ev))
-        a.hcount = next((v - ev for v in vals if v >= ev), 0)
-        if a.aromatic and a.z in (7, 15) and len(a.nbrs) == 3:
-            a.hcount = 0
+        if a.aromatic:
+            # RDKit (Atom::calcImplicitValence): an aromatic atom is only ever completed to its LOWEST default valence --
+            # thiophene's s (explicit 3 > 2), an N-substituted pyrrole n (4 > 3) and furan's o get no hydrogen.  (Found
+            # by tests/test_featurize_inchi_cpu.py: every thiophene of the reference's Esper table had one H too many
+            # against its InChI formula while the rule tried S's next valence, 4.)
+            a.hcount = max(vals[0] - ev, 0)
+        else:
+            a.hcount = next((v - ev for v in vals if v >= ev), 0)
 
 
 def _rings(atoms: List[_Atom], bonds: List[_Bond]) -> List[List[int]]:

@@ -89,8 +89,12 @@ def envelope(name, draws=None):
             pb, gp, nm = permuted_copy(batch, 1000 * d + 17)
             per_draw.append(distances(run_model(m, pb, target, torch.float32), ref, gp, nm))
     keys = per_draw[0].keys()
+    half = max(draws // 2, 1)
     return {"draws": draws, "nodes": int(batch.x.size(0)),
             "max": {k: max(p[k] for p in per_draw) for k in keys},
+            # the same over the first half only: equivalent presentations of the batch at the UNPERTURBED weights
+            # (the tighter yardstick, asserted wherever the HIP path already meets it)
+            "max_perm": {k: max(p[k] for p in per_draw[:half]) for k in keys},
             "median": {k: sorted(p[k] for p in per_draw)[draws // 2] for k in keys},
             "unpermuted": per_draw[0]}
 

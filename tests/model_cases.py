@@ -65,6 +65,9 @@ MODEL_CASES: Dict[str, Tuple[dict, dict]] = {
     "pna_cfg2_full_1024": (dict(hidden_dim=128, propagation_depth=6), dict(graphs=1024, gen=2)),
     "gine_cfg3_full_1024": (dict(conv="GINE", hidden_dim=256, propagation_depth=6), dict(graphs=1024, gen=3)),
     "pna_cfg5_shaped": (dict(hidden_dim=512, towers=4, propagation_depth=2), dict(graphs=448, gen=5)),
+    # BASELINE configs[4] at its full depth (H = 512, T = 4, L = 6) on 448 skewed graphs: the yardstick of the full-size
+    # train-mode property test (tests/test_full_size_gpu.py)
+    "pna_cfg5_l6_shaped": (dict(hidden_dim=512, towers=4, propagation_depth=6), dict(graphs=448, gen=5)),
 }
 
 

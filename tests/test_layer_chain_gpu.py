@@ -1,0 +1,125 @@
+"""Teacher-forced layer-chain parity: every layer of a DEEP model on its REAL input.
+
+tests/test_conv_gpu.py holds one conv layer to 1e-5 on synthetic ``randn().relu()`` inputs; tests/test_model_gpu.py holds
+whole models to the reference's own fp32 reproducibility envelope (up to 0.5 on an intermediate's gradient).  Between the
+two: the fp64 oracle (``oracle/pyg_restatement.py``, restating the wiring of
+/root/reference/gnnepcsaft/train/models.py:196-227) is run once through the whole model and the loss; then, for EVERY
+layer l, the native ``conv_l -> BatchNorm_l -> ReLU`` is fed the oracle's own input of layer l (cast to fp32 -- the
+activations a deep model really produces: post-BatchNorm-ReLU rows, |mean| / std of the conv output ~ 20) and the
+oracle's own upstream gradient, and its output and ALL gradients (input, bond table, every parameter of the conv and of
+the BatchNorm) are compared with the fp64 oracle ON THE SAME fp32-cast input at the north-star 1e-5.
+
+No error propagates from layer to layer, so -- as in the single-layer test -- the rounding band of every discrete
+decision is rigorous: node rows holding one (std mask, near-tied extremum, hidden ReLU at 0: tests/conv_parity.py) are
+dropped from the forward comparison and their upstream gradient is zeroed; BatchNorm outputs inside the band of the
+following ReLU's kink get a zero upstream gradient element-wise.  Both exclusions are COUNTED and asserted small.
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import pyg_restatement as O
+from tests.conv_parity import LIN_BAND_ULPS, bond_codes, gine_event_rows, pna_event_rows
+from tests.model_cases import build_case
+from tests.parity_util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _oracle_chain(o64, batch, target):
+    """One fp64 forward + loss + backward of the oracle, keeping every layer's input and the gradient at its output."""
+    x = o64.node_embed(batch.x)
+    ea = o64.edge_embed(batch.edge_attr)
+    acts = [x]
+    for conv, bn in zip(o64.convs, o64.batch_norms):
+        a = torch.relu(bn(conv(x=acts[-1], edge_index=batch.edge_index, edge_attr=ea)))
+        a.retain_grad()
+        acts.append(a)
+    pred = o64.mlp(o64.global_pool(acts[-1], batch.batch))
+    loss = O.ape_huber_loss(pred, getattr(batch, target).double())
+    loss.backward()
+    return [a.detach() for a in acts[:-1]], [a.grad.detach() for a in acts[1:]]
+
+
+@pytest.mark.parametrize("name", ["pna_cfg2_full_1024", "pna_cfg5_shaped", "gine_cfg3_full_1024"])
+def test_every_layer_on_the_deep_models_real_activations(gpu_device, name):
+    from gnnepcsaft_amd import ops
+    from gnnepcsaft_amd.train.models import GNNePCSAFT
+    cfg, batch, target = build_case(name)
+    torch.manual_seed(0)
+    o32 = O.GNNePCSAFT(cfg).train()
+    state = copy.deepcopy(o32.state_dict())
+    o64 = copy.deepcopy(o32).double().train()
+    inputs, upstream = _oracle_chain(o64, batch, target)
+    o64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in state.items()})  # running stats back
+    o64.zero_grad()
+
+    native = GNNePCSAFT(cfg)
+    native.load_state_dict(state, strict=True)
+    native = native.to(gpu_device).train()
+    b = batch.to(gpu_device)
+    N = batch.x.size(0)
+    pack = ops.pack_graph(b.edge_index, b.edge_attr, b.batch, N, int(batch.num_graphs))
+    code = bond_codes(batch.edge_attr)
+    pna = cfg["conv"] == "PNA"
+    u = 2.0 ** -24
+    worst = {}
+    for l in range(cfg["propagation_depth"]):
+        x32 = inputs[l].float()                      # teacher forcing: the oracle's input of layer l, as fp32 holds it
+        g32 = upstream[l].float()
+        conv64, bn64 = copy.deepcopy(o64.convs[l]), copy.deepcopy(o64.batch_norms[l])
+        # ---- fp64 arbiter on the fp32-cast input
+        with torch.no_grad():
+            table64 = o64.edge_embed(native.edge_embed.combos.cpu())          # the 60 bond-feature combinations
+            ev = (pna_event_rows if pna else gine_event_rows)(conv64, x32.double(), batch.edge_index,
+                                                              table64.index_select(0, code))
+        rows = ev["rows"]
+        xx = x32.double().requires_grad_(True)
+        be = table64.detach().clone().requires_grad_(True)
+        y = conv64(x=xx, edge_index=batch.edge_index, edge_attr=be.index_select(0, code))
+        z = bn64(y)
+        bnm = bn64.module
+        near_kink = z.detach().abs() <= LIN_BAND_ULPS * u * ((z.detach() - bnm.bias).abs() + bnm.bias.abs())
+        g = g32.double() * (~rows).unsqueeze(1) * (~near_kink)
+        torch.relu(z).backward(g)
+        ref_out = torch.relu(z).detach()
+        ref_grads = {"conv." + n: p.grad for n, p in conv64.named_parameters()}
+        ref_grads.update({"bn." + n: p.grad for n, p in bn64.named_parameters()})
+        # ---- native conv + BatchNorm(+ReLU) on the same fp32 tensors
+        nconv, nbn = native.convs[l], native.batch_norms[l]
+        native.zero_grad(set_to_none=True)
+        xn = x32.to(gpu_device).requires_grad_(True)
+        ben = table64.float().to(gpu_device).requires_grad_(True)
+        out = nbn(nconv(x=xn, edge_index=pack, edge_attr=ben), relu=True)
+        out.backward(g.float().to(gpu_device))
+        torch.cuda.synchronize()
+        got = {"conv." + n: p.grad for n, p in nconv.named_parameters()}
+        got.update({"bn." + n: p.grad for n, p in nbn.named_parameters()})
+        # ---- the CPU fp32 oracle on the same tensors (printed beside the HIP path's errors, not asserted)
+        c32, b32 = copy.deepcopy(o32.convs[l]), copy.deepcopy(o32.batch_norms[l])
+        c32.zero_grad()
+        b32.zero_grad()
+        x3 = x32.clone().requires_grad_(True)
+        be3 = table64.float().requires_grad_(True)
+        o3 = torch.relu(b32(c32(x=x3, edge_index=batch.edge_index, edge_attr=be3.index_select(0, code))))
+        o3.backward(g.float())
+        cpu = {"out": rel_err(o3.detach()[~rows], ref_out[~rows]), "dx": rel_err(x3.grad, xx.grad), "dbe": rel_err(be3.grad, be.grad)}
+        # ---- bookkeeping + comparison
+        keep = ~rows
+        n_excl, n_kink = int(rows.sum()), int(near_kink.sum())
+        assert n_excl <= max(2, N // 50), (name, l, "event rows", n_excl, N)           # <= 2 % of the rows
+        assert n_kink <= max(8, z.numel() // 2000), (name, l, "BatchNorm outputs at the ReLU kink", n_kink)
+        errs = {"out": rel_err(out.detach().cpu()[keep], ref_out[keep]), "dx": rel_err(xn.grad.cpu(), xx.grad),
+                "dbe": rel_err(ben.grad.cpu(), be.grad)}
+        G = max(float(v.abs().max()) for v in ref_grads.values())
+        for n_, ref in ref_grads.items():  # (biases in front of a BatchNorm have an analytically zero gradient: floor)
+            errs["d" + n_] = rel_err(got[n_].cpu(), ref, floor=1e-3 * G)
+        bad = {k: v for k, v in errs.items() if v > TOL}
+        worst[l] = max(errs.values())
+        print(f"{name} layer {l}: hip out {errs['out']:.1e} dx {errs['dx']:.1e} dbe {errs['dbe']:.1e} worst dparam "
+              f"{max(v for k, v in errs.items() if k.startswith('dconv') or k.startswith('dbn')):.1e} | cpu fp32 out "
+              f"{cpu['out']:.1e} dx {cpu['dx']:.1e} dbe {cpu['dbe']:.1e} | excluded rows {n_excl}/{N}, kink entries {n_kink}")
+        assert not bad, (name, "layer", l, bad, {"rows_excluded": n_excl, "kink_entries": n_kink})
+    print(name, "worst error per layer:", {l: f"{v:.1e}" for l, v in worst.items()})
