@@ -15,6 +15,14 @@
 // accumulator order, the aggregate with k_pna_agg_fwd's operation order over the same rows, so h1 / m / A are bit-identical
 // to the unfused path's (tests/test_fused_gpu.py).
 //
+// Measured and rejected (round 3, same box, cfg-2's layer shape, 102 vs 100 us): a ROLE-SPECIALISED form of this kernel --
+// waves 0-3 only multiply (64 rows x 32 columns each) and park the result tile, waves 4-7 gather / split the next tile and
+// reduce / store the previous one, every common-path store unconditional (clamped duplicates) so that hipcc can count the
+// stores behind an in-flight gather.  It was bit-identical and no faster: the phases of a tile are latency-bound, not
+// throughput-bound (one wave per SIMD issues a dependent VALU chain at half the rate of two), so giving the reduction to
+// half the waves doubled its length.  In-kernel stamps of THIS kernel (tools/ubench/edge_fwd_stamp.hip): issue of the next
+// tile's 25 loads 19 %, MFMAs 15 %, result tile -> LDS 4 %, gather wait + split 11 %, stores + reduction 26 %, barriers 25 %.
+//
 // Edge tiles (gnx_edge_tiles): tile j holds every node whose FIRST CSR position lies in [W j, W (j + 1)); with in-degrees
 // <= maxdeg and W = 65 - maxdeg a tile never exceeds 64 message rows.  A violated bound (a degree above the hint) sets
 // sticky range-flag bit 6 and the overflowing rows are dropped (no out-of-bounds access).

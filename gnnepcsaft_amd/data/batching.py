@@ -3,7 +3,7 @@
 Replaces, for the hot path only, what the reference gets from torch_geometric's ``DataLoader`` →
 ``Batch.from_data_list`` (call sites ``/root/reference/gnnepcsaft/train/train.py:19,59-75``) and
 ``calc_deg`` (``/root/reference/gnnepcsaft/train/utils.py:37-60``).  Integer work only; results are bit-exact
-with the oracle's collate (tests/test_batching.py).  The device-side CSR packing lives in ``csrc/gnx_pack.hip``.
+with the oracle's collate (tests/test_host_cpu.py::test_collate_bit_exact_with_oracle).  The device-side CSR packing lives in ``csrc/gnx_pack.hip``.
 """
 from __future__ import annotations
 

@@ -15,6 +15,11 @@
  *    Only gnx_check_range (integer input validation read-back) and gnx_prof_end synchronise that stream.
  *  - all float tensors are fp32 row-major; "ld" = leading dimension in elements.  Index tensors handed over by the
  *    caller in the reference's layout are int64; everything the library produces is int32.
+ *  - NO gnx_comm_* entry points (SURVEY.md §8b lists gnx_comm_init / gnx_allreduce_f32 as the stand-in for Lightning
+ *    DDP's gradient exchange, ref: train/train.py:85-88): the exchange is torch.distributed's "nccl" backend = the RCCL
+ *    that PyTorch-ROCm bundles, driven by gnnepcsaft_amd/dp.py on this library's side stream (gnx_side_stream).  A second
+ *    RCCL linked into this library would live beside torch's copy in the same process; gnx_scale (below) is the only
+ *    arithmetic of the exchange (sum -> average).
  *  - no hidden global state except the opaque gnx_handle (device id, stream, options, profiling events).  The GNX_*
  *    environment variables are read ONCE, in gnx_create, as initial option values; no entry point reads the
  *    environment afterwards (gnx_set_option changes an option at run time).

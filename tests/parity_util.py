@@ -180,26 +180,45 @@ def compare_with_oracle(cfg: dict, batch, device: str = "cuda:0", seed: int = 0,
 
 
 _ENVELOPE = None
+_TIGHT = None
 
 
-def reference_envelope(case: str) -> Dict[str, float]:
-    """Recorded fp32 reproducibility envelope of the reference algorithm on a case of tests/model_cases.py."""
+def reference_envelope(case: str, kind: str = "max") -> Dict[str, float]:
+    """Recorded fp32 reproducibility envelope of the reference algorithm on a case of tests/model_cases.py.
+    ``kind``: "max" = over all draws (equivalent presentations of the batch, half of them with every weight moved by
+    <= 4 fp32 roundings); "max_perm" = over the presentations at the UNPERTURBED weights only (the tighter yardstick)."""
     global _ENVELOPE
     if _ENVELOPE is None:
         import json
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conditioning.json")
         _ENVELOPE = json.load(open(path))["cases"]
-    return _ENVELOPE[case]["max"]
+    return _ENVELOPE[case][kind]
+
+
+def tight_cases() -> set:
+    """Cases on which the HIP path already stays inside the PERMUTATION-ONLY envelope with room to spare (measured by
+    tools/model_parity_survey.py on an MI355X, committed as tests/golden/tight_cases.json): they are asserted against
+    that tighter envelope (VERDICT r2 next #3); the others against the envelope that also perturbs the weights."""
+    global _TIGHT
+    if _TIGHT is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tight_cases.json")
+        _TIGHT = set(json.load(open(path))["cases"]) if os.path.exists(path) else set()
+    return _TIGHT
 
 
 NORTH_STAR = 1e-5
 ENVELOPE_SLACK = 1.5
 
 
-def parity_bounds(res: Dict[str, float], case: str) -> Dict[str, float]:
-    """Per metric: max(1e-5, 1.5 x max(recorded envelope, this run's CPU fp32 distance to fp64))."""
-    env = reference_envelope(case)
+def parity_bounds(res: Dict[str, float], case: str, kind: Optional[str] = None) -> Dict[str, float]:
+    """Per metric: max(1e-5, 1.5 x max(recorded envelope, this run's CPU fp32 distance to fp64)).  The envelope is the
+    permutation-only one for the cases of ``tight_cases()`` (or when ``kind`` says so), else the one over all draws."""
+    if kind is None:
+        kind = "max_perm" if case in tight_cases() else "max"
+    env = reference_envelope(case, kind)
     live = {"pred": res["pred_cpu64"], "loss": res["loss_cpu64"], "grad_l2": res["grad_l2_cpu64"],
             "grad_max": res["grad_max_cpu64"], "inter": max(res["inter_cpu64"].values()),
             "dinter": max(res["dinter_cpu64"].values())}
