@@ -14,7 +14,7 @@ ABI_VERSION = 3
 GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
 # gnx_set_option ids (include/gnx.h)
 OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
-    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED = range(11)
+    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS = range(12)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
@@ -75,7 +75,25 @@ class PnaBwdArgs(C.Structure):
                 ("params", C.POINTER(_vp)), ("grads", C.POINTER(_vp)), ("dout", _vp),
                 ("gbuf", _vp * PNA_MAX_LAYERS), ("dA", _vp), ("gebuf", _vp * PNA_MAX_LAYERS), ("dP", _vp), ("dQ", _vp),
                 ("dTe", _vp), ("dEE", _vp), ("dWm", _vp), ("dbm", _vp), ("dWeff", _vp), ("ws", _vp), ("ws_bytes", _sz),
-                ("acc_buf", _vp), ("dx", _vp)]
+                ("acc_buf", _vp), ("dx", _vp), ("defer_small", _i32), ("_pad2", _i32)]
+
+
+class PnaFinishArgs(C.Structure):
+    """gnx_pna_finish_args of include/gnx.h (same field order)."""
+    _fields_ = [("L", _i32), ("T", _i32), ("F", _i32), ("pre_layers", _i32), ("post_layers", _i32), ("R", _i32), ("D", _i32),
+                ("merged", _i32), ("use_side_streams", _i32), ("_pad", _i32),
+                ("BE", _vp), ("acc_buf", _vp), ("ones", _vp), ("avg_deg_log", C.POINTER(_f32)),
+                ("params", C.POINTER(_vp)), ("grads", C.POINTER(_vp)), ("EE", C.POINTER(_vp)), ("dTe", C.POINTER(_vp)),
+                ("dEE", C.POINTER(_vp)), ("dWm", C.POINTER(_vp)), ("dbm", C.POINTER(_vp)), ("dWeff", C.POINTER(_vp))]
+
+
+class SmallProb(C.Structure):
+    """gnx_small_prob of include/gnx.h."""
+    _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("bias", _vp), ("C", _vp), ("ldc", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("flags", _i32)]
+
+
+SB_A_TRANS, SB_B_TRANS, SB_ACCUMULATE, SB_ATOMIC, SB_RELU = 1, 2, 4, 8, 16
 
 # every symbol include/gnx.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -141,6 +159,12 @@ SIGNATURES = {
     "gnx_pna_weight_only": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, C.POINTER(_vp), _i32, _vp, _vp,
                                    C.POINTER(_vp), _vp, _vp]),
     "gnx_pna_conv_fwd": (_i32, [_vp, C.POINTER(PnaFwdArgs)]),
+    "gnx_pna_weight_only_all": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_vp),
+                                       _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "gnx_pna_stack_finish": (_i32, [_vp, C.POINTER(PnaFinishArgs)]),
+    "gnx_gemm_small_batched": (_i32, [_vp, _i32, C.POINTER(SmallProb)]),
+    "gnx_pna_weff_batched": (_i32, [_vp, _i32, C.POINTER(_vp), _i64, _i32, _i32, C.POINTER(_f32), C.POINTER(_vp)]),
+    "gnx_pna_weff_bwd_batched": (_i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, C.POINTER(_f32), C.POINTER(_vp), _i64]),
     "gnx_pna_conv_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "gnx_pna_conv_bwd": (_i32, [_vp, C.POINTER(PnaBwdArgs)]),
     "gnx_fill": (_i32, [_vp, _vp, _i64, _f32]),

@@ -48,7 +48,8 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
               {GNX_OPT_WGRAD_WGS, "GNX_WGRAD_WGS", 0},         {GNX_OPT_AGG_BWD_RECOMPUTE, "GNX_AGG_BWD_RECOMPUTE", 1},
               {GNX_OPT_EMBED_BWD_MFMA, "GNX_EMBED_BWD_MFMA", 1}, {GNX_OPT_STD_BWD_CENTERED, "GNX_STD_BWD_CENTERED", 1},
               {GNX_OPT_GEMM_PIPE, "GNX_GEMM_PIPE", 1},
-              {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1},       {GNX_OPT_EDGE_FUSED, "GNX_EDGE_FUSED", 1}};
+              {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1},       {GNX_OPT_EDGE_FUSED, "GNX_EDGE_FUSED", 1},
+              {GNX_OPT_SIDE_CUS, "GNX_SIDE_CUS", 0}};
   for (const auto& o : opts) {
     const char* e = getenv(o.env);
     h->opt[o.id] = e ? atoi(e) : o.def;
@@ -97,7 +98,20 @@ static int32_t side_ensure(gnx_handle* h, int which) {
                 gnx_handle::kSideStreams);
   if (h->side[which] == nullptr) {
     GNX_HIP(hipSetDevice(h->device));
-    GNX_HIP(hipStreamCreateWithFlags(&h->side[which], hipStreamNonBlocking));
+    // GNX_OPT_SIDE_CUS (A/B): side stream 0 (weight gradients) confined to that many CUs, spread evenly
+    // over the chip, so that the memory-bound kernels of the main stream keep the rest to themselves
+    const int want = which == 0 ? h->opt[GNX_OPT_SIDE_CUS] : 0;
+    const int ncu = h->num_cus > 0 ? h->num_cus : 256;
+    if (want > 0 && want < ncu) {
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int k = 0; k < want; ++k) {
+        const int cu = (int)(((int64_t)k * ncu) / want);
+        mask[cu >> 5] |= 1u << (cu & 31);
+      }
+      GNX_HIP(hipExtStreamCreateWithCUMask(&h->side[which], (uint32_t)mask.size(), mask.data()));
+    } else {
+      GNX_HIP(hipStreamCreateWithFlags(&h->side[which], hipStreamNonBlocking));
+    }
     GNX_HIP(hipEventCreateWithFlags(&h->side_fork[which], hipEventDisableTiming));
     GNX_HIP(hipEventCreateWithFlags(&h->side_done[which], hipEventDisableTiming));
   }

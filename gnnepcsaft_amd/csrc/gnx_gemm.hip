@@ -1515,6 +1515,101 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched small products: up to GNX_SMALL_BATCH independent problems of k_gemm_small's kind in ONE launch (the 60-row
+// bond-table chain, the merged lin o last-post weights and their gradients for ALL layers of a model; VERDICT r2 #4:
+// ~360 launches per step, 54 of them 16 x 16-patch products of ~8 us each).  blockIdx.y = problem, blockIdx.x = output
+// patch.  Either operand may be read transposed (the weight gradients of these tiny layers are A^T B products), the
+// result may be accumulated plainly (problems of one launch must then write disjoint outputs) or with fp32 atomics.
+// Same k-ordered fmaf chain and K chunking as k_gemm_small: bit-identical results for the untransposed forms.
+// ---------------------------------------------------------------------------------------------------------------
+struct small_batch_args {
+  gnx_small_prob p[GNX_SMALL_BATCH];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) k_gemm_small_batched(small_batch_args b) {
+  __shared__ float As[SM_T][SM_KC + 1];
+  __shared__ float Bs[SM_T][SM_KC + 1];
+  const gnx_small_prob& q = b.p[blockIdx.y];
+  const int M = q.M, N = q.N, K = q.K;
+  const int nt = (N + SM_T - 1) / SM_T, mt = (M + SM_T - 1) / SM_T;
+  if ((int)blockIdx.x >= nt * mt) return;  // (uniform per workgroup: before any barrier)
+  const int m0 = (blockIdx.x / nt) * SM_T, n0 = (blockIdx.x % nt) * SM_T;
+  const bool at = (q.flags & GNX_SB_A_TRANS) != 0, bt = (q.flags & GNX_SB_B_TRANS) != 0;
+  const float* __restrict__ A = q.A;
+  const float* __restrict__ B = q.B;
+  const int64_t lda = q.lda, ldb = q.ldb;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SM_KC) {
+    const int kc = (K - k0) < SM_KC ? (K - k0) : SM_KC;
+    if (!at) {  // A[m][k]: consecutive threads along k
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int r = i / SM_KC, k = i % SM_KC;
+        As[r][k] = (m0 + r < M && k < kc) ? A[(int64_t)(m0 + r) * lda + k0 + k] : 0.f;
+      }
+    } else {  // A[k][m]: consecutive threads along m
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int k = i / SM_T, r = i % SM_T;
+        As[r][k] = (m0 + r < M && k < kc) ? A[(int64_t)(k0 + k) * lda + m0 + r] : 0.f;
+      }
+    }
+    if (bt) {  // B[n][k]
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int r = i / SM_KC, k = i % SM_KC;
+        Bs[r][k] = (n0 + r < N && k < kc) ? B[(int64_t)(n0 + r) * ldb + k0 + k] : 0.f;
+      }
+    } else {  // B[k][n]
+      for (int i = threadIdx.x; i < SM_T * SM_KC; i += 256) {
+        const int k = i / SM_T, r = i % SM_T;
+        Bs[r][k] = (n0 + r < N && k < kc) ? B[(int64_t)(k0 + k) * ldb + n0 + r] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < SM_KC; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+    __syncthreads();
+  }
+  const int gm = m0 + ty, gn = n0 + tx;
+  if (gm < M && gn < N) {
+    float v = acc + (q.bias != nullptr ? q.bias[gn] : 0.f);
+    float* cp = q.C + (int64_t)gm * q.ldc + gn;
+    if (q.flags & GNX_SB_ATOMIC) {
+      atomicAdd(cp, v);
+    } else {
+      if (q.flags & GNX_SB_ACCUMULATE) v += *cp;
+      *cp = (q.flags & GNX_SB_RELU) ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+extern "C" int32_t gnx_gemm_small_batched(gnx_handle* h, int32_t nprob, const gnx_small_prob* probs) {
+  GNX_CHECK_ARG(h && nprob >= 0 && (probs || nprob == 0), "gnx_gemm_small_batched: bad argument");
+  for (int32_t i0 = 0; i0 < nprob; i0 += GNX_SMALL_BATCH) {
+    small_batch_args b;
+    b.n = nprob - i0 < GNX_SMALL_BATCH ? nprob - i0 : GNX_SMALL_BATCH;
+    int maxt = 0;
+    double bytes = 0.0, flops = 0.0;
+    for (int i = 0; i < b.n; ++i) {
+      const gnx_small_prob& q = probs[i0 + i];
+      GNX_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "gnx_gemm_small_batched: problem %d is empty or NULL",
+                    i0 + i);
+      GNX_CHECK_ARG(!((q.flags & GNX_SB_ATOMIC) && (q.flags & GNX_SB_RELU)), "gnx_gemm_small_batched: atomic + relu");
+      b.p[i] = q;
+      const int t = (int)(gnx_cdiv(q.M, SM_T) * gnx_cdiv(q.N, SM_T));
+      maxt = t > maxt ? t : maxt;
+      bytes += 4.0 * ((double)q.M * (q.K + q.N) + (double)q.N * q.K);
+      flops += 2.0 * q.M * q.N * q.K;
+    }
+    for (int i = b.n; i < GNX_SMALL_BATCH; ++i) b.p[i] = b.p[0];
+    gnx_prof_scope prof(h, GNX_K_GEMM_SMALL, bytes, flops, 0.0);
+    hipLaunchKernelGGL(k_gemm_small_batched, dim3((unsigned)maxt, (unsigned)b.n), dim3(256), 0, h->stream, b);
+    GNX_LAUNCH_CHECK();
+  }
+  return GNX_OK;
+}
+
 // Which products take the split-operand tiled kernel (k_split_weights -> k_gemm3) and how many bytes of split weight
 // images they need.  Shared by gnx_gemm_workspace_bytes and the launch path so both always agree.
 static size_t gemm_split_bytes(const gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
@@ -2481,6 +2576,111 @@ __global__ void k_pna_weff_bwd(const float* __restrict__ dWeff, int F, int D, fl
   w[F + j] += s1;
   w[5 * F + j] += s2;
   w[9 * F + j] += s3;
+}
+
+// the same for up to GNX_SMALL_BATCH (layer, tower) pairs in one launch (blockIdx.y = pair)
+struct weff_batch_args {
+  const float* W[GNX_SMALL_BATCH];
+  float* out[GNX_SMALL_BATCH];
+  float avg_log[GNX_SMALL_BATCH];
+  int64_t ldw;
+  int F, D;
+};
+
+__global__ void k_pna_weff_batched(weff_batch_args a) {
+  const int b = blockIdx.y;
+  const int F = a.F;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t per = (int64_t)F * 4 * F;
+  if (i >= per * a.D) return;
+  int d = (int)(i / per);
+  int o = (int)((i % per) / (4 * F)), j = (int)(i % (4 * F));
+  float dd = (float)d;
+  float amp = logf(dd + 1.0f) / a.avg_log[b];
+  float att = a.avg_log[b] / logf(fmaxf(dd, 1.0f) + 1.0f);
+  const float* w = a.W[b] + (int64_t)o * a.ldw;
+  a.out[b][i] = w[F + j] + amp * w[5 * F + j] + att * w[9 * F + j];
+}
+
+struct weff_bwd_batch_args {
+  const float* dWeff[GNX_SMALL_BATCH];
+  float* dW[GNX_SMALL_BATCH];
+  float avg_log[GNX_SMALL_BATCH];
+  int64_t lddw;
+  int F, D;
+};
+
+__global__ void k_pna_weff_bwd_batched(weff_bwd_batch_args a) {
+  const int b = blockIdx.y;
+  const int F = a.F;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t per = (int64_t)F * 4 * F;
+  if (i >= per) return;
+  int o = (int)(i / (4 * F)), j = (int)(i % (4 * F));
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float avg_log = a.avg_log[b];
+  const float* dWeff = a.dWeff[b];
+  for (int d = 0; d < a.D; ++d) {  // same order and expressions as k_pna_weff_bwd
+    float dd = (float)d;
+    float amp = logf(dd + 1.0f) / avg_log;
+    float att = avg_log / logf(fmaxf(dd, 1.0f) + 1.0f);
+    float v = dWeff[(int64_t)d * per + i];
+    s1 += v;
+    s2 += amp * v;
+    s3 += att * v;
+  }
+  float* w = a.dW[b] + (int64_t)o * a.lddw;
+  w[F + j] += s1;
+  w[5 * F + j] += s2;
+  w[9 * F + j] += s3;
+}
+
+extern "C" int32_t gnx_pna_weff_bwd_batched(gnx_handle* h, int32_t n, const float* const* dWeff, int32_t F, int32_t D,
+                                            const float* avg_deg_log, float* const* dW, int64_t lddw) {
+  GNX_CHECK_ARG(h && dWeff && dW && avg_deg_log && n >= 0 && F > 0 && D > 0 && lddw >= 13 * F,
+                "gnx_pna_weff_bwd_batched: bad argument");
+  const int64_t cnt = (int64_t)F * 4 * F;
+  for (int32_t i0 = 0; i0 < n; i0 += GNX_SMALL_BATCH) {
+    weff_bwd_batch_args a;
+    const int m = n - i0 < GNX_SMALL_BATCH ? n - i0 : GNX_SMALL_BATCH;
+    for (int i = 0; i < GNX_SMALL_BATCH; ++i) {
+      const int k = i < m ? i0 + i : i0;
+      a.dWeff[i] = dWeff[k];
+      a.dW[i] = dW[k];
+      a.avg_log[i] = avg_deg_log[k];
+      GNX_CHECK_ARG(a.dWeff[i] && a.dW[i], "gnx_pna_weff_bwd_batched: NULL pointer at %d", k);
+    }
+    a.lddw = lddw;
+    a.F = F;
+    a.D = D;
+    hipLaunchKernelGGL(k_pna_weff_bwd_batched, dim3((unsigned)gnx_cdiv(cnt, 256), (unsigned)m), dim3(256), 0, h->stream, a);
+    GNX_LAUNCH_CHECK();
+  }
+  return GNX_OK;
+}
+
+// W[i] / out[i]: HOST arrays of n device pointers (post_nns[t][0].weight [F,13F] -> Weff [D,F,4F]); avg_log: HOST [n]
+extern "C" int32_t gnx_pna_weff_batched(gnx_handle* h, int32_t n, const float* const* W, int64_t ldw, int32_t F, int32_t D,
+                                        const float* avg_deg_log, float* const* Weff) {
+  GNX_CHECK_ARG(h && W && Weff && avg_deg_log && n >= 0 && F > 0 && D > 0 && ldw >= 13 * F, "gnx_pna_weff_batched: bad argument");
+  const int64_t cnt = (int64_t)F * 4 * F * D;
+  for (int32_t i0 = 0; i0 < n; i0 += GNX_SMALL_BATCH) {
+    weff_batch_args a;
+    const int m = n - i0 < GNX_SMALL_BATCH ? n - i0 : GNX_SMALL_BATCH;
+    for (int i = 0; i < GNX_SMALL_BATCH; ++i) {
+      const int k = i < m ? i0 + i : i0;
+      a.W[i] = W[k];
+      a.out[i] = Weff[k];
+      a.avg_log[i] = avg_deg_log[k];
+      GNX_CHECK_ARG(a.W[i] && a.out[i], "gnx_pna_weff_batched: NULL pointer at %d", k);
+    }
+    a.ldw = ldw;
+    a.F = F;
+    a.D = D;
+    hipLaunchKernelGGL(k_pna_weff_batched, dim3((unsigned)gnx_cdiv(cnt, 256), (unsigned)m), dim3(256), 0, h->stream, a);
+    GNX_LAUNCH_CHECK();
+  }
+  return GNX_OK;
 }
 
 extern "C" int32_t gnx_pna_weff(gnx_handle* h, const float* W, int64_t ldw, int32_t F, int32_t D, float avg_deg_log,

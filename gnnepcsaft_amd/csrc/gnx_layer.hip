@@ -112,9 +112,13 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   float* g = a->gbuf[gi];
   const float* z_last = a->zs[a->n_z - 1];
   int last_hidden;
+  const bool defer = a->defer_small != 0;  // small accumulators pre-zeroed by the caller, their consumers run in
+                                           // gnx_pna_stack_finish for all layers at once
   if (a->merged) {
-    GNX_TRY(gnx_fill(h, a->dWm, (int64_t)H * H, 0.f));
-    GNX_TRY(gnx_fill(h, a->dbm, H, 0.f));
+    if (!defer) {
+      GNX_TRY(gnx_fill(h, a->dWm, (int64_t)H * H, 0.f));
+      GNX_TRY(gnx_fill(h, a->dbm, H, 0.f));
+    }
     wq.add(a->dout, H, z_last, H, N, H, H, a->dWm, H, a->dbm);
     gnx_gemm_seg s = seg(a->dout, H, a->Wm, H, H);
     GNX_TRY(gnx_gemm(h, 1, &s, N, H, nullptr, z_last, H, g, H, 0, a->ws, a->ws_bytes));
@@ -144,11 +148,11 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     float* dWp = G[k];
     wq.add(gt, H, a->x + t * F, H, N, F, F, dWp, 13 * F, G[k + 1]);
     float* dWeff = a->dWeff + (int64_t)t * D * F * 4 * F;
-    GNX_TRY(gnx_fill(h, dWeff, (int64_t)D * F * 4 * F, 0.f));
+    if (!defer) GNX_TRY(gnx_fill(h, dWeff, (int64_t)D * F * 4 * F, 0.f));
     GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
       GNX_TRY(gnx_gemm_wgrad_grouped(h, gt, H, At, (int64_t)T * 4 * F, N, F, 4 * F, dWeff, 4 * F, (int64_t)F * 4 * F, a->dperm,
                                      a->chunks, a->nchunks, a->max_chunks));
-      return gnx_pna_weff_bwd(h, dWeff, F, D, a->avg_deg_log, dWp, 13 * F);
+      return defer ? GNX_OK : gnx_pna_weff_bwd(h, dWeff, F, D, a->avg_deg_log, dWp, 13 * F);
     }));
     gnx_gemm_seg s = seg(gt, H, a->weff[t], 4 * F, F);
     const int64_t stride = (int64_t)4 * F * F;
@@ -184,8 +188,9 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   }
   // ---- bond-table gradient chain on side stream 1 (feeds parameter gradients and the shared accumulator only)
   GNX_TRY(on_side(h, 1, side, [&]() -> int32_t {
-    GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
+    if (!defer) GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
     if (E > 0) GNX_TRY(gnx_key_segment_sum(h, ge, a->code_pos, a->code, E, H, a->dTe));
+    if (defer) return GNX_OK;
     for (int t = 0; t < T; ++t) {
       const int k0 = pidx(t, true, 0);
       GNX_TRY(gnx_gemm_wgrad(h, a->dTe + t * F, H, a->EE, F, nullptr, R, F, F, G[k0] + 2 * F, 3 * F, G[k0 + 1]));
@@ -200,7 +205,7 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   // ---- the layer's weight gradients in batched launches on side stream 0, then what hangs off dWm
   GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
     GNX_TRY(wq.flush(h));
-    if (!a->merged) return GNX_OK;
+    if (!a->merged || defer) return GNX_OK;
     const float* dbm = a->dbm;
     for (int t = 0; t < T; ++t) {
       const int k = pidx(t, false, post - 1);
@@ -321,4 +326,136 @@ extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
     }
   gnx_gemm_seg sl = a->merged ? seg(a->zs[zi], H, a->Wm, H, H) : seg(a->zs[zi], H, W[2], H, H);
   return gnx_gemm(h, 1, &sl, N, H, a->merged ? a->bm : W[3], nullptr, 0, a->out, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Model-level batching of the weight-only work.  Everything below depends on weights (and 60-row
+// tables) only; issued per layer it was ~14 launches of ~5-10 us each per layer and direction.  Here: all layers at once.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+inline gnx_small_prob sprob(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                            int M, int N, int K, int flags) {
+  gnx_small_prob q;
+  q.A = A;
+  q.lda = lda;
+  q.B = B;
+  q.ldb = ldb;
+  q.bias = bias;
+  q.C = C;
+  q.ldc = ldc;
+  q.M = M;
+  q.N = N;
+  q.K = K;
+  q.flags = flags;
+  return q;
+}
+}  // namespace
+
+extern "C" int32_t gnx_pna_weight_only_all(gnx_handle* h, int32_t L, const float* BE, int32_t R, int32_t T, int32_t F,
+                                           int32_t pre_layers, int32_t post_layers, int32_t D, const float* avg_deg_log,
+                                           const float* const* params, int32_t merged, float* const* EE, float* const* Te,
+                                           float* const* weff, float* const* Wm, float* const* bm) {
+  GNX_CHECK_ARG(h && BE && params && EE && Te && avg_deg_log && L >= 1 && R > 0 && T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 1 &&
+                    pre_layers >= 1 && post_layers >= 1, "gnx_pna_weight_only_all: bad argument");
+  GNX_CHECK_ARG(!merged || (Wm && bm && post_layers > 1), "gnx_pna_weight_only_all: merged without Wm / bm");
+  GNX_CHECK_ARG(D <= 0 || weff, "gnx_pna_weight_only_all: weff is NULL");
+  const int H = T * F, per = 2 * (pre_layers + post_layers), np = 4 + T * per;
+  std::vector<gnx_small_prob> first, second;
+  std::vector<const float*> wsrc;
+  std::vector<float*> wdst;
+  std::vector<float> wavg;
+  for (int l = 0; l < L; ++l) {
+    const float* const* P = params + (size_t)l * np;
+    // EE = BondEmb W_enc^T + b_enc
+    first.push_back(sprob(BE, H, P[0], H, P[1], EE[l], F, R, F, H, GNX_SB_B_TRANS));
+    for (int t = 0; t < T; ++t) {
+      const float* W0 = P[4 + t * per];
+      // Te[:, t] = EE W_e^T + b  (the edge slice of pre-layer 0 on the bond table): needs EE -> second launch
+      second.push_back(sprob(EE[l], F, W0 + 2 * F, 3 * F, P[4 + t * per + 1], Te[l] + t * F, H, R, F, F, GNX_SB_B_TRANS));
+      if (D > 0) {
+        wsrc.push_back(P[4 + t * per + 2 * pre_layers]);
+        wdst.push_back(weff[(size_t)l * T + t]);
+        wavg.push_back(avg_deg_log[l]);
+      }
+      if (merged) {
+        const int k = 4 + t * per + 2 * (pre_layers + post_layers - 1);
+        // Wm[:, t] = lin_w[:, t] @ W_last_t ;  bm (+)= b_last_t @ lin_w[:, t]^T (+ lin_b with the first tower)
+        first.push_back(sprob(P[2] + t * F, H, P[k], F, nullptr, Wm[l] + t * F, H, H, F, F, 0));
+        if (t == 0)
+          first.push_back(sprob(P[k + 1], F, P[2], H, P[3], bm[l], H, 1, H, F, GNX_SB_B_TRANS));
+        else  // further towers add on top of the first one's result: atomics, one launch later
+          second.push_back(sprob(P[k + 1], F, P[2] + t * F, H, nullptr, bm[l], H, 1, H, F, GNX_SB_B_TRANS | GNX_SB_ATOMIC));
+      }
+    }
+  }
+  GNX_TRY(gnx_gemm_small_batched(h, (int32_t)first.size(), first.data()));
+  GNX_TRY(gnx_gemm_small_batched(h, (int32_t)second.size(), second.data()));
+  if (D > 0)
+    GNX_TRY(gnx_pna_weff_batched(h, (int32_t)wsrc.size(), wsrc.data(), 13 * F, F, D, wavg.data(), wdst.data()));
+  return GNX_OK;
+}
+
+extern "C" int32_t gnx_pna_stack_finish(gnx_handle* h, const gnx_pna_finish_args* a) {
+  GNX_CHECK_ARG(h && a, "gnx_pna_stack_finish: NULL argument");
+  const int L = a->L, T = a->T, F = a->F, pre = a->pre_layers, post = a->post_layers, R = a->R, D = a->D;
+  GNX_CHECK_ARG(L >= 1 && T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 1 && pre >= 1 && post >= 1 && R >= 1 && D >= 1,
+                "gnx_pna_stack_finish: bad shape");
+  GNX_CHECK_ARG(a->BE && a->acc_buf && a->ones && a->avg_deg_log && a->params && a->grads && a->EE && a->dTe && a->dEE &&
+                    a->dWeff && (!a->merged || (a->dWm && a->dbm)), "gnx_pna_stack_finish: NULL array");
+  const int H = T * F, per = 2 * (pre + post), np = 4 + T * per;
+  const bool side = a->use_side_streams != 0;
+  // ---- side stream 1: from every layer's dTe (by-code segment sums) to the bond-embedding gradient
+  GNX_TRY(on_side(h, 1, side, [&]() -> int32_t {
+    std::vector<gnx_small_prob> s1, s2;
+    for (int l = 0; l < L; ++l) {
+      const float* const* P = a->params + (size_t)l * np;
+      float* const* G = a->grads + (size_t)l * np;
+      for (int t = 0; t < T; ++t) {
+        const int k0 = 4 + t * per;
+        const float* dTe = a->dTe[l] + t * F;
+        // d W0[:, 2F:3F] += dTe_t^T EE ;  d b0 += column sums of dTe_t ;  dEE += dTe_t W0[:, 2F:3F]
+        s1.push_back(sprob(dTe, H, a->EE[l], F, nullptr, G[k0] + 2 * F, 3 * F, F, F, R, GNX_SB_A_TRANS | GNX_SB_ACCUMULATE));
+        s1.push_back(sprob(a->ones, R, dTe, H, nullptr, G[k0 + 1], F, 1, F, R, GNX_SB_ACCUMULATE));
+        s1.push_back(sprob(dTe, H, P[k0] + 2 * F, 3 * F, nullptr, a->dEE[l], F, R, F, F, GNX_SB_ATOMIC));
+      }
+      // d W_enc += dEE^T BondEmb ;  d b_enc += column sums of dEE ;  acc += dEE W_enc
+      s2.push_back(sprob(a->dEE[l], F, a->BE, H, nullptr, G[0], H, F, H, R, GNX_SB_A_TRANS | GNX_SB_ACCUMULATE));
+      s2.push_back(sprob(a->ones, R, a->dEE[l], F, nullptr, G[1], F, 1, F, R, GNX_SB_ACCUMULATE));
+      s2.push_back(sprob(a->dEE[l], F, P[0], H, nullptr, a->acc_buf, H, R, H, F, GNX_SB_ATOMIC));
+    }
+    GNX_TRY(gnx_gemm_small_batched(h, (int32_t)s1.size(), s1.data()));
+    return gnx_gemm_small_batched(h, (int32_t)s2.size(), s2.data());
+  }));
+  // ---- side stream 0, behind the layers' weight gradients: lin / last post layer from dWm, dbm; post-layer 0 from dWeff
+  GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
+    std::vector<const float*> dweff;
+    std::vector<float*> dwp;
+    std::vector<float> avg;
+    std::vector<gnx_small_prob> u1, u2;
+    for (int l = 0; l < L; ++l) {
+      const float* const* P = a->params + (size_t)l * np;
+      float* const* G = a->grads + (size_t)l * np;
+      for (int t = 0; t < T; ++t) {
+        dweff.push_back(a->dWeff[(size_t)l * T + t]);
+        dwp.push_back(G[4 + t * per + 2 * pre]);
+        avg.push_back(a->avg_deg_log[l]);
+        if (!a->merged) continue;
+        const int k = 4 + t * per + 2 * (pre + post - 1);
+        const float* dWm = a->dWm[l] + t * F;
+        const float* lin_w = P[2] + t * F;
+        // d lin_w[:, t] += dWm[:, t] W_t^T (+ dbm b_t^T, one launch later: same output) ;  dW_t += lin_w[:, t]^T dWm[:, t] ;
+        // db_t += dbm lin_w[:, t]
+        u1.push_back(sprob(dWm, H, P[k], F, nullptr, G[2] + t * F, H, H, F, F, GNX_SB_B_TRANS | GNX_SB_ACCUMULATE));
+        u2.push_back(sprob(a->dbm[l], 1, P[k + 1], 1, nullptr, G[2] + t * F, H, H, F, 1, GNX_SB_B_TRANS | GNX_SB_ACCUMULATE));
+        u1.push_back(sprob(lin_w, H, dWm, H, nullptr, G[k], F, F, F, H, GNX_SB_A_TRANS | GNX_SB_ACCUMULATE));
+        u1.push_back(sprob(a->dbm[l], H, lin_w, H, nullptr, G[k + 1], F, 1, F, H, GNX_SB_ACCUMULATE));
+      }
+      if (a->merged)  // d lin_b += dbm
+        u1.push_back(sprob(a->ones, 1, a->dbm[l], H, nullptr, G[3], H, 1, H, 1, GNX_SB_ACCUMULATE));
+    }
+    GNX_TRY(gnx_pna_weff_bwd_batched(h, (int32_t)dweff.size(), dweff.data(), F, D, avg.data(), dwp.data(), 13 * F));
+    GNX_TRY(gnx_gemm_small_batched(h, (int32_t)u1.size(), u1.data()));
+    return gnx_gemm_small_batched(h, (int32_t)u2.size(), u2.data());
+  }));
+  return GNX_OK;
 }

@@ -39,6 +39,19 @@ def prepare_ahead_enabled() -> bool:
 _BOND_CHAIN_ASIDE = True
 _NATIVE_LAYER_BWD = True
 _FUSED_EDGE = True
+_BATCH_WEIGHT_ONLY = True
+
+
+def set_batch_weight_only(enabled: bool) -> None:
+    """A/B switch: the weight-only work of ALL PNA layers of a model in a few batched launches -- forward: bond-table chain,
+    Weff(d), merged lin o last-post weights (gnx_pna_weight_only_all); backward: their gradients, deferred to the end of
+    the pass (gnx_pna_stack_finish) -- instead of ~14 small launches per layer and direction (default on)."""
+    global _BATCH_WEIGHT_ONLY
+    _BATCH_WEIGHT_ONLY = bool(enabled)
+
+
+def batch_weight_only_enabled() -> bool:
+    return _BATCH_WEIGHT_ONLY
 
 
 def set_fused_edge(enabled: bool) -> None:
@@ -316,6 +329,61 @@ class BondGradAccumulator:
         self.buf = torch.empty(R, H, dtype=torch.float32, device=device)
         self.depth = depth
         self.encoder = None  # (combos, offsets, tables) of the BondEncoder whose table() this gradient belongs to
+        # deferred small work (functional.set_batch_weight_only): every PNA layer's backward leaves its 60-row bond-table
+        # chain, its lin o last-post un-merge and its Weff gradient to ONE batched finish at the end of the pass
+        self.defer = False
+        self.slab = None      # zero-filled fp32 slab: [acc.buf | per layer: dTe, dEE, dWm, dbm, dWeff x T]
+        self.deferred = []    # per deferring layer: dict of what gnx_pna_stack_finish needs (keeps the tensors alive)
+
+    def layer_slab(self, layer_index: int, R: int, H: int, F: int, T: int, D: int, device):
+        """This layer's zeroed accumulators (dTe [R,H], dEE [R,F], dWm [H,H], dbm [H], dWeff [T,D,F,4F]) inside the slab
+        shared by the model's layers: ONE fill launch per backward pass, issued by the layer whose backward runs first
+        (which also stands in for clearing ``buf``, the slab's first R x H entries)."""
+        per = R * H + R * F + H * H + H + T * D * F * 4 * F
+        if self.slab is None:
+            self.slab = ops.zeros(R * H + self.depth * per, device=device)
+            self.buf = self.slab[:R * H].view(R, H)
+        o = R * H + layer_index * per
+        out = []
+        for n in (R * H, R * F, H * H, H, T * D * F * 4 * F):
+            out.append(self.slab[o:o + n])
+            o += n
+        return out
+
+    def finish_deferred(self, device) -> None:
+        """gnx_pna_stack_finish over the layers that deferred (side stream 1: bond chain tails; side stream 0: un-merge and
+        Weff gradients, behind the layers' weight gradients)."""
+        if not self.deferred:
+            return
+        import ctypes as C
+        from . import _lib
+        d0 = self.deferred[0]
+        L = len(self.deferred)
+        T, F, pre, post, R, D, merged = d0["T"], d0["F"], d0["pre"], d0["post"], d0["R"], d0["D"], d0["merged"]
+        np_ = 4 + T * 2 * (pre + post)
+        a = _lib.PnaFinishArgs()
+        a.L, a.T, a.F, a.pre_layers, a.post_layers, a.R, a.D, a.merged = L, T, F, pre, post, R, D, int(merged)
+        a.use_side_streams = int(ops.wgrad_stream_enabled())
+        ones = ops.ones_vector(device, max(R, 1))
+        a.BE, a.acc_buf, a.ones = d0["BE"].data_ptr(), self.buf.data_ptr(), ones.data_ptr()
+        avg = (C.c_float * L)(*[d["avg"] for d in self.deferred])
+        vp = C.c_void_p
+        params = (vp * (L * np_))(*[p.data_ptr() for d in self.deferred for p in d["params"]])
+        grads = (vp * (L * np_))(*[g.data_ptr() for d in self.deferred for g in d["sinks"]])
+        EE = (vp * L)(*[d["EE"].data_ptr() for d in self.deferred])
+        dTe = (vp * L)(*[d["dTe"].data_ptr() for d in self.deferred])
+        dEE = (vp * L)(*[d["dEE"].data_ptr() for d in self.deferred])
+        dWm = (vp * L)(*[d["dWm"].data_ptr() for d in self.deferred])
+        dbm = (vp * L)(*[d["dbm"].data_ptr() for d in self.deferred])
+        per_w = D * F * 4 * F
+        dWeff = (vp * (L * T))(*[d["dWeff"].data_ptr() + 4 * t * per_w for d in self.deferred for t in range(T)])
+        a.avg_deg_log = C.cast(avg, C.POINTER(C.c_float))
+        for name, arr in (("params", params), ("grads", grads), ("EE", EE), ("dTe", dTe), ("dEE", dEE), ("dWm", dWm),
+                          ("dbm", dbm), ("dWeff", dWeff)):
+            setattr(a, name, C.cast(arr, C.POINTER(vp)))
+        ops.check(_lib.load().gnx_pna_stack_finish(_lib.handle(device), C.byref(a)))
+        ops.keep_until_join(device, [self.slab, ones] + [t for d in self.deferred for t in (d["BE"], d["EE"], *d["params"], *d["sinks"])])
+        self.deferred = []
 
     def first_in_backward(self, layer_index: int) -> bool:
         return layer_index == self.depth - 1
@@ -354,6 +422,52 @@ class WeightOnlyAhead:
     def wait(self):
         ops.join_side_stream(self.device)
         return self.value
+
+
+class WeightOnlyAll:
+    """``_pna_weight_only`` of ALL PNA layers of a model in three launches (gnx_pna_weight_only_all: batched 60-row products
+    + batched Weff), issued on the library's side stream when enabled; ``get(l)`` orders the caller's stream behind them
+    (once) and returns layer l's (EE, Te, weffs, Wm, bm).  ``layers``: per layer (avg_deg_log, params) with identical
+    T / F / pre_layers / post_layers."""
+
+    def __init__(self, BE, T, F, pre_layers, post_layers, layers, D):
+        import ctypes as C
+        from . import _lib
+        self.device = BE.device
+        L, R, H = len(layers), BE.size(0), T * F
+        merged = post_layers > 1 and _MERGE_LAST_POST
+        f32 = dict(dtype=torch.float32, device=BE.device)
+        EE = torch.empty(L, R, F, **f32)
+        Te = torch.empty(L, R, H, **f32)
+        weff = torch.empty(L, T, D, F, 4 * F, **f32) if D > 0 else None
+        Wm = torch.empty(L, H, H, **f32) if merged else None
+        bm = torch.empty(L, H, **f32) if merged else None
+        vp = C.c_void_p
+        np_ = len(layers[0][1])
+        avg = (C.c_float * L)(*[float(a_) for a_, _ in layers])
+        params = (vp * (L * np_))(*[p.data_ptr() for _, ps in layers for p in ps])
+        ptrs = lambda t_, n: (vp * n)(*[t_[i].data_ptr() for i in range(n)]) if t_ is not None else None  # noqa: E731
+        a_EE, a_Te, a_Wm, a_bm = ptrs(EE, L), ptrs(Te, L), ptrs(Wm, L), ptrs(bm, L)
+        a_weff = (vp * (L * T))(*[weff[l, t].data_ptr() for l in range(L) for t in range(T)]) if weff is not None else None
+        cast = lambda arr: None if arr is None else C.cast(arr, C.POINTER(vp))  # noqa: E731
+
+        def launch():
+            ops.check(_lib.load().gnx_pna_weight_only_all(
+                _lib.handle(BE.device), L, BE.data_ptr(), R, T, F, pre_layers, post_layers, D,
+                C.cast(avg, C.POINTER(C.c_float)), cast(params), int(merged), cast(a_EE), cast(a_Te), cast(a_weff),
+                cast(a_Wm), cast(a_bm)))
+
+        keep = [BE, EE, Te, weff, Wm, bm] + [p for _, ps in layers for p in ps]
+        ops.run_after_wgrads(BE, keep, launch)
+        self.values = [(EE[l], Te[l], [weff[l, t] for t in range(T)] if weff is not None else [],
+                        Wm[l] if merged else None, bm[l] if merged else None) for l in range(L)]
+        self._joined = False
+
+    def get(self, l: int):
+        if not self._joined:
+            ops.join_side_stream(self.device)
+            self._joined = True
+        return self.values[l]
 
 
 def _merge_last_post_with_lin(lin_w, lin_b, last, sl, like):
@@ -452,7 +566,16 @@ def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_po
     gebuf = torch.empty(pre_layers, max(E, 1), H, **f32)
     dA = torch.empty(N, T * 4 * F, **f32)
     pq = torch.empty(2, N, H, **f32)
-    small = torch.empty(R * H + R * F + H * H + H + T * D * F * 4 * F, **f32)
+    # small accumulators: private scratch, or (deferral) zeroed slices of the model's slab that stay alive until the ONE
+    # batched finish at the end of the pass; a data-parallel exchange that hands every layer's slice to RCCL the moment
+    # its launches are issued (ops.set_wgrad_done_hook) needs the layer's gradients complete here: no deferral then
+    defer = _BATCH_WEIGHT_ONLY and acc is not None and ops._WGRAD_DONE_HOOK is None and \
+        (acc.slab is not None or acc.first_in_backward(ctx.layer_index))  # pylint: disable=protected-access
+    if defer:
+        dTe_t, dEE_t, dWm_t, dbm_t, dWeff_t = acc.layer_slab(ctx.layer_index, R, H, F, T, D, dev)
+        small = None
+    else:
+        small = torch.empty(R * H + R * F + H * H + H + T * D * F * 4 * F, **f32)
     dx = torch.empty(N, H, **f32)
     lib = _lib.load()
     ws_bytes = lib.gnx_pna_conv_bwd_workspace_bytes(T, F, D)
@@ -483,18 +606,29 @@ def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_po
     for i in range(pre_layers):
         a.gebuf[i] = gebuf[i].data_ptr()
     a.dA, a.dP, a.dQ = dA.data_ptr(), pq[0].data_ptr(), pq[1].data_ptr()
-    base, o = small.data_ptr(), 0
-    a.dTe, o = base + 4 * o, o + R * H
-    a.dEE, o = base + 4 * o, o + R * F
-    a.dWm, o = base + 4 * o, o + H * H
-    a.dbm, o = base + 4 * o, o + H
-    a.dWeff = base + 4 * o
+    if defer:
+        a.dTe, a.dEE, a.dWm, a.dbm, a.dWeff = (t_.data_ptr() for t_ in (dTe_t, dEE_t, dWm_t, dbm_t, dWeff_t))
+        a.defer_small = 1
+        acc.deferred.append(dict(T=T, F=F, pre=pre_layers, post=post_layers, R=R, D=D, merged=merged, avg=float(avg_deg_log),
+                                 BE=BE, EE=EE, params=list(params), sinks=list(sinks), dTe=dTe_t, dEE=dEE_t, dWm=dWm_t,
+                                 dbm=dbm_t, dWeff=dWeff_t))
+    else:
+        base, o = small.data_ptr(), 0
+        a.dTe, o = base + 4 * o, o + R * H
+        a.dEE, o = base + 4 * o, o + R * F
+        a.dWm, o = base + 4 * o, o + H * H
+        a.dbm, o = base + 4 * o, o + H
+        a.dWeff = base + 4 * o
+        a.defer_small = 0
     a.ws, a.ws_bytes, a.acc_buf, a.dx = ws.data_ptr(), ws_bytes, acc.buf.data_ptr(), dx.data_ptr()
     ops.pna_conv_bwd(a, dev)
     # everything the side-stream launches touch stays alive until the join at the end of backward
     ops.keep_until_join(dev, [dout, x, BE, EE, A, *hs, *zs, *ctx.weffs, ctx.Wm, gbuf, gebuf, dA, pq, small, ws, acc.buf,
-                              *params, *sinks])
-    dBE = acc.handoff(dev) if ctx.layer_index == 0 else None
+                              acc.slab, *params, *sinks])
+    dBE = None
+    if ctx.layer_index == 0:  # the last conv backward of the pass: the deferred small work, then the bond encoder's own
+        acc.finish_deferred(dev)
+        dBE = acc.handoff(dev)
     ops.finish_backward(dev, True, sinks)
     return (dx, dBE, None, None, *([None] * len(params)))
 

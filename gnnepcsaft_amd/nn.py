@@ -53,6 +53,11 @@ class Dropout(Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training or self.p == 0.0:
             return x
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the mask counter is a host integer passed to the kernel by value: a captured step would replay ONE mask for
+            # ever (and the checkpointed counter would stop advancing) -- refuse instead of silently training wrong
+            raise RuntimeError("Dropout(p > 0) cannot be captured into a HIP graph: its per-call mask counter lives on the "
+                               "host; run the training step eagerly (bench.py --launch eager)")
         self.calls += 1
         return Fn.DropoutFn.apply(x, self.p, self.seed, self.calls)
 
@@ -208,6 +213,19 @@ class PNAConv(Module):
         dc = edge_index.degree_classes(edge_index.max_degree_hint) if Fn._USE_DEGREE_CLASSES else None
         return Fn.WeightOnlyAhead(edge_attr, self.towers, self.F_in, self.pre_layers, self.post_layers,
                                   self.aggr_module.avg_log(), self._params(), dc.D if dc is not None else 0)
+
+    @staticmethod
+    def prepare_all(convs: Sequence["PNAConv"], edge_index: GraphPack, edge_attr: torch.Tensor) -> "Fn.WeightOnlyAll":
+        """The weight-only work of every layer of a stack of identically shaped PNAConv layers in three batched launches
+        (on the side stream when enabled); pass ``.get(l)`` to layer l's ``forward(prepared=...)``."""
+        c0 = convs[0]
+        if any((c.towers, c.F_in, c.pre_layers, c.post_layers) != (c0.towers, c0.F_in, c0.pre_layers, c0.post_layers)
+               for c in convs):
+            raise ValueError("prepare_all needs identically shaped PNAConv layers")
+        dc = edge_index.degree_classes(edge_index.max_degree_hint) if Fn._USE_DEGREE_CLASSES else None
+        layers = [(c.aggr_module.avg_log(), c._params()) for c in convs]
+        return Fn.WeightOnlyAll(edge_attr, c0.towers, c0.F_in, c0.pre_layers, c0.post_layers, layers,
+                                dc.D if dc is not None else 0)
 
     def forward(self, x: torch.Tensor, edge_index: GraphPack, edge_attr: torch.Tensor, prepared=None, bond_acc=None,
                 layer_index: int = 0) -> torch.Tensor:

@@ -50,6 +50,20 @@ def zeros(*shape: int, device: torch.device) -> torch.Tensor:
     return zero_(t)
 
 
+_ONES: dict = {}
+
+
+def ones_vector(device: torch.device, n: int) -> torch.Tensor:
+    """A cached fp32 vector of >= n ones on ``device`` (column sums as 1 x R products in gnx_gemm_small_batched)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _ONES.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 256), dtype=torch.float32, device=device)
+        check(_lib.load().gnx_fill(handle(device), t.data_ptr(), t.numel(), 1.0))
+        _ONES[key] = t
+    return t
+
+
 def zero_(t: torch.Tensor) -> torch.Tensor:
     if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
         if t.numel():

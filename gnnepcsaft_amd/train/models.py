@@ -155,8 +155,11 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
         # weight-only work of PNA layer l+1 (bond-table chain, Weff(d), merged lin o last post layer: ~5 tiny dependent
         # launches) is issued on the library's side stream while layer l runs, so it leaves the critical path
         convs = list(self.convs)
-        ahead = None
-        if h.is_cuda and ops.wgrad_stream_enabled() and Fn.prepare_ahead_enabled() and hasattr(convs[0], "prepare_ahead"):
+        ahead = ahead_all = None
+        if h.is_cuda and Fn.batch_weight_only_enabled() and isinstance(convs[0], gnn.PNAConv) and convs[0].towers <= 8:
+            # ... of ALL layers in three launches (60-row products and Weff(d) batched over the layers)
+            ahead_all = gnn.PNAConv.prepare_all(convs, pack, bond_table)
+        elif h.is_cuda and ops.wgrad_stream_enabled() and Fn.prepare_ahead_enabled() and hasattr(convs[0], "prepare_ahead"):
             ahead = convs[0].prepare_ahead(pack, bond_table)
         # every layer's bond-embedding gradient is accumulated into one buffer on a side stream (its chain feeds no
         # activation gradient); layer 0, whose backward runs last, returns the total
@@ -166,7 +169,9 @@ class GNNePCSAFT(torch.nn.Module):  # pylint: disable=R0902
             acc.encoder = (self.edge_embed.combos, self.edge_embed.offsets, self.edge_embed._weights())
         for l, (layer, norm) in enumerate(zip(convs, self.batch_norms)):
             extra = {} if acc is None else {"bond_acc": acc, "layer_index": l}
-            if ahead is not None:
+            if ahead_all is not None:
+                extra["prepared"] = ahead_all.get(l)
+            elif ahead is not None:
                 extra["prepared"] = ahead.wait()
                 ahead = convs[l + 1].prepare_ahead(pack, bond_table) if l + 1 < len(convs) else None
             # PNA and GINE both take edge_attr (reference :211-214); the ReLU is fused into the BatchNorm kernel

@@ -67,7 +67,8 @@ enum {
   GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
   GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd takes the fused gather -> pre-layer 1 -> aggregate kernel when eligible (bit-identical results) */
-  GNX_OPT_COUNT = 11
+  GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
+  GNX_OPT_COUNT = 12
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
@@ -205,6 +206,27 @@ typedef struct {
 } gnx_wgrad_prob;
 int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gnx_wgrad_prob* probs);
 
+/* several independent SMALL products (M, N <= a few hundred rows: the 60-row bond-table chain, the merged H x H weights
+ * and their gradients) in one launch -- for all layers of a model at once instead of ~9 launches of ~8 us per layer:
+ *     C (+)= act( op(A) op(B) + bias )     op(A) = A [M,K] or, with GNX_SB_A_TRANS, A stored [K,M] (a TN weight gradient);
+ *                                          op(B): GNX_SB_B_TRANS = B stored [N,K] (torch weight layout), else [K,N].
+ * GNX_SB_ACCUMULATE: plain read-modify-write (outputs of the launch's problems must then be disjoint);
+ * GNX_SB_ATOMIC: fp32 atomic adds (several problems may add into one output; the output must be initialised). */
+enum { GNX_SB_A_TRANS = 1, GNX_SB_B_TRANS = 2, GNX_SB_ACCUMULATE = 4, GNX_SB_ATOMIC = 8, GNX_SB_RELU = 16 };
+#define GNX_SMALL_BATCH 32
+typedef struct {
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  const float* bias; /* [N] or NULL */
+  float* C;
+  int64_t ldc;
+  int32_t M, N, K;
+  int32_t flags;
+} gnx_small_prob;
+int32_t gnx_gemm_small_batched(gnx_handle* h, int32_t nprob, const gnx_small_prob* probs); /* probs: HOST array */
+
 /* ---- in-degree classes: PNA post-layer 0 with one effective weight per degree ------------------------------- */
 /* amp/att of [3P] DegreeScalerAggregation depend on the in-degree d only, so
  *     [x | A | amp*A | att*A] W^T  =  x W0^T + A (W1 + amp(d) W2 + att(d) W3)^T  =  x W0^T + A Weff(d)^T
@@ -237,6 +259,11 @@ int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, con
 int32_t gnx_pna_weff(gnx_handle* h, const float* W, int64_t ldw, int32_t F, int32_t D, float avg_deg_log, float* Weff);
 int32_t gnx_pna_weff_bwd(gnx_handle* h, const float* dWeff, int32_t F, int32_t D, float avg_deg_log, float* dW,
                          int64_t lddw);
+/* gnx_pna_weff for n (layer, tower) pairs in one launch: W / Weff HOST arrays of n device pointers, avg_deg_log HOST [n] */
+int32_t gnx_pna_weff_batched(gnx_handle* h, int32_t n, const float* const* W, int64_t ldw, int32_t F, int32_t D,
+                             const float* avg_deg_log, float* const* Weff);
+int32_t gnx_pna_weff_bwd_batched(gnx_handle* h, int32_t n, const float* const* dWeff, int32_t F, int32_t D,
+                                 const float* avg_deg_log, float* const* dW, int64_t lddw);
 
 /* ---- PNA message assembly (first pre-layer folded to node level) ------------------------------------------- */
 /* h1[p,:] = relu(P[dst[p],:] + Q[src[p],:] + Te[code[p],:])  for CSR position p;  width = H.
@@ -395,9 +422,41 @@ typedef struct {
   size_t ws_bytes;
   float* acc_buf;                             /* [R,H] bond-embedding gradient accumulator shared by the model's layers */
   float* dx;                                  /* [N,H] out: gradient w.r.t. the layer input */
+  int32_t defer_small;                        /* 1: dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
+                                                 gnx_pna_stack_finish, which runs every layer's 60-row bond-table chain, its
+                                                 lin o last-post un-merge and its Weff gradient in a few batched launches */
+  int32_t _pad2;
 } gnx_pna_bwd_args;
 size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D);
 int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* args);
+
+/* What gnx_pna_conv_bwd(defer_small = 1) left out, for ALL L layers of a model in ~6 launches (instead of ~14 per layer):
+ * side stream 1: pre-layer-0 edge-slice / edge_encoder gradients and the bond-embedding gradient (atomic adds into acc_buf,
+ * which the caller zeroed) from every layer's dTe; side stream 0 (behind the layers' weight gradients): lin / last-post
+ * gradients from dWm / dbm, and post-layer 0's A-block gradients from dWeff.  Pointer arrays are HOST arrays; params /
+ * grads hold L x (4 + T 2 (pre + post)) device pointers in gnx_pna_bwd_args' order; ones: device fp32[>= R] of 1.0. */
+typedef struct {
+  int32_t L, T, F, pre_layers, post_layers, R, D, merged, use_side_streams, _pad;
+  const float* BE;
+  float* acc_buf;
+  const float* ones;
+  const float* avg_deg_log;        /* HOST [L] */
+  const float* const* params;      /* HOST [L * np] */
+  float* const* grads;             /* HOST [L * np] */
+  const float* const* EE;          /* HOST [L]: [R,F] */
+  float* const* dTe;               /* HOST [L]: [R,H]  (by-code segment sums, complete on side stream 1) */
+  float* const* dEE;               /* HOST [L]: [R,F]  zero-initialised */
+  const float* const* dWm;         /* HOST [L]: [H,H]  (merged = 1) */
+  const float* const* dbm;         /* HOST [L]: [H] */
+  const float* const* dWeff;       /* HOST [L * T]: [D,F,4F] */
+} gnx_pna_finish_args;
+int32_t gnx_pna_stack_finish(gnx_handle* h, const gnx_pna_finish_args* args);
+/* gnx_pna_weight_only for all L layers of a model in 3 launches: avg_deg_log HOST [L]; params HOST [L * np]; EE / Te / Wm /
+ * bm HOST [L]; weff HOST [L * T] (D > 0). */
+int32_t gnx_pna_weight_only_all(gnx_handle* h, int32_t L, const float* BE, int32_t R, int32_t T, int32_t F,
+                                int32_t pre_layers, int32_t post_layers, int32_t D, const float* avg_deg_log,
+                                const float* const* params, int32_t merged, float* const* EE, float* const* Te,
+                                float* const* weff, float* const* Wm, float* const* bm);
 
 /* the weight-only part of a PNAConv forward in one call: EE [R,F], Te [R,H], Weff(d) [D,F,4F] per tower (D > 0) and, with
  * merged = 1 (post_layers > 1), Wm [H,H] = lin_w @ blockdiag(W_last_t), bm [H] = lin_w b_last + lin_b.  `params` as in

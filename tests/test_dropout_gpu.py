@@ -107,3 +107,20 @@ def test_model_with_dropout_matches_oracle_on_the_same_masks(gpu_device, conv, k
     num = sum(float(((gn[n].cpu().double() - go[n].double()) ** 2).sum()) for n in go)
     den = sum(float((go[n].double() ** 2).sum()) for n in go)
     assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
+
+
+def test_dropout_refuses_hip_graph_capture(gpu_device):
+    """the mask counter is a host integer, so a captured training step would replay one mask for ever: the layer
+    raises under stream capture instead (p = 0 and eval mode stay capturable: no launch)."""
+    from gnnepcsaft_amd import nn as gnn
+    drop = gnn.Dropout(p=0.25).train()
+    x = torch.randn(64, 32, device=gpu_device)
+    s = torch.cuda.Stream(device=gpu_device)
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                drop(x)
+    torch.cuda.synchronize()
+    assert drop.calls == 0
+    assert drop.eval()(x) is x

@@ -173,3 +173,45 @@ def test_model_with_and_without_the_fused_edge_kernel(gpu_device, name):
     for n in g0:
         # (fp32 atomics of the weight gradients arrive in another order every run: 1e-4 of 1 % of the largest entry)
         assert rel_err(g1[n], g0[n], floor=1e-2 * G) <= (1e-4 if big else 0.2), n
+
+
+@pytest.mark.parametrize("name", ["pna_small", "pna_towers4", "pna_cfg2_shape_256", "pna_pre1_post1", "pna_hubs"])
+def test_batched_weight_only_work_equals_the_per_layer_launches(gpu_device, name):
+    """The weight-only work of all layers in a few batched launches (gnx_pna_weight_only_all forward, gnx_pna_stack_finish
+    at the end of backward) vs the per-layer launch sequences: the forward products are the same k-ordered fmaf chains
+    (bit-identical predictions and loss); the deferred gradients re-associate a few 60-row sums (1e-5 of the largest
+    gradient entry).  Needs in-place gradient sinks (the training configuration: flat gradient buffer)."""
+    from gnnepcsaft_amd import dp, ops
+    from gnnepcsaft_amd import functional as Fn
+    from gnnepcsaft_amd.train.models import GNNePCSAFT
+    from tests.model_cases import build_case
+    cfg, batch, target = build_case(name)
+    torch.manual_seed(0)
+    model = GNNePCSAFT(cfg).to("cuda:0").train()
+    state = copy.deepcopy(model.state_dict())
+    b = batch.to("cuda:0")
+    flat = dp.FlatGradAllReduce(model)
+    Fn.set_grad_in_place(True)
+    ops.set_wgrad_side_stream(True)
+    out = {}
+    try:
+        for batched in (True, False):
+            Fn.set_batch_weight_only(batched)
+            model.load_state_dict(state)
+            flat.zero_grad()
+            pred = model(b.x, b.edge_index, b.edge_attr, b.batch)
+            loss, _ = Fn.HuberAPEFn.apply(pred, getattr(b, target), 0.01)
+            loss.backward()
+            torch.cuda.synchronize()
+            out[batched] = (pred.detach().clone(), loss.detach().clone(), flat.flat.detach().clone())
+    finally:
+        Fn.set_batch_weight_only(True)
+        Fn.set_grad_in_place(False)
+        ops.set_wgrad_side_stream(False)
+    (p1, l1, g1), (p0, l0, g0) = out[True], out[False]
+    if cfg["towers"] == 1:
+        assert torch.equal(p1, p0) and torch.equal(l1, l0)
+    else:  # the merged bias sums its towers' contributions with atomics in the batched form: last-bit differences
+        assert rel_err(p1, p0) <= 1e-5 and rel_err(l1, l0) <= 1e-6
+    assert float((g1 - g0).abs().max()) <= (1e-5 if cfg["towers"] == 1 else 2e-3) * float(g0.abs().max()), \
+        float((g1 - g0).abs().max() / g0.abs().max())

@@ -11,8 +11,9 @@ the BatchNorm) are compared with the fp64 oracle ON THE SAME fp32-cast input at 
 
 No error propagates from layer to layer, so -- as in the single-layer test -- the rounding band of every discrete
 decision is rigorous: node rows holding one (std mask, near-tied extremum, hidden ReLU at 0: tests/conv_parity.py) are
-dropped from the forward comparison and their upstream gradient is zeroed; BatchNorm outputs inside the band of the
-following ReLU's kink get a zero upstream gradient element-wise.  Both exclusions are COUNTED and asserted small.
+dropped from the forward comparison and their upstream gradient is zeroed; BatchNorm outputs closer to the following
+ReLU's kink than the forward tolerance, propagated through the BatchNorm scale |gamma| / sigma, get a zero upstream
+gradient element-wise.  Both exclusions are COUNTED and asserted small (<= 2 % of the rows, <= 0.2 % of the entries).
 """
 import copy
 
@@ -20,7 +21,7 @@ import pytest
 import torch
 
 from oracle import pyg_restatement as O
-from tests.conv_parity import LIN_BAND_ULPS, bond_codes, gine_event_rows, pna_event_rows
+from tests.conv_parity import bond_codes, gine_event_rows, pna_event_rows
 from tests.model_cases import build_case
 from tests.parity_util import rel_err
 
@@ -64,7 +65,6 @@ def test_every_layer_on_the_deep_models_real_activations(gpu_device, name):
     pack = ops.pack_graph(b.edge_index, b.edge_attr, b.batch, N, int(batch.num_graphs))
     code = bond_codes(batch.edge_attr)
     pna = cfg["conv"] == "PNA"
-    u = 2.0 ** -24
     worst = {}
     for l in range(cfg["propagation_depth"]):
         x32 = inputs[l].float()                      # teacher forcing: the oracle's input of layer l, as fp32 holds it
@@ -81,7 +81,15 @@ def test_every_layer_on_the_deep_models_real_activations(gpu_device, name):
         y = conv64(x=xx, edge_index=batch.edge_index, edge_attr=be.index_select(0, code))
         z = bn64(y)
         bnm = bn64.module
-        near_kink = z.detach().abs() <= LIN_BAND_ULPS * u * ((z.detach() - bnm.bias).abs() + bnm.bias.abs())
+        # A BatchNorm output closer to the following ReLU's kink than what the forward tolerance maps to cannot be decided at
+        # that tolerance: the conv output is held to TOL x max|y| (norm-wise), BatchNorm multiplies an error of the conv
+        # output by |gamma| / sigma -- and max|y| / sigma is ~ 20-50 on these activations, which is why "one layer on randn"
+        # said nothing about this.  Those entries get a zero upstream gradient on both sides (element-wise, counted).
+        with torch.no_grad():
+            yd = y.detach()
+            sigma = (yd.var(dim=0, unbiased=False) + bnm.eps).sqrt()
+            band = TOL * float(yd.abs().max()) * bnm.weight.detach().abs() / sigma
+            near_kink = z.detach().abs() <= band
         g = g32.double() * (~rows).unsqueeze(1) * (~near_kink)
         torch.relu(z).backward(g)
         ref_out = torch.relu(z).detach()
@@ -110,7 +118,7 @@ def test_every_layer_on_the_deep_models_real_activations(gpu_device, name):
         keep = ~rows
         n_excl, n_kink = int(rows.sum()), int(near_kink.sum())
         assert n_excl <= max(2, N // 50), (name, l, "event rows", n_excl, N)           # <= 2 % of the rows
-        assert n_kink <= max(8, z.numel() // 2000), (name, l, "BatchNorm outputs at the ReLU kink", n_kink)
+        assert n_kink <= max(8, z.numel() // 500), (name, l, "BatchNorm outputs at the ReLU kink", n_kink)  # <= 0.2 %
         errs = {"out": rel_err(out.detach().cpu()[keep], ref_out[keep]), "dx": rel_err(xn.grad.cpu(), xx.grad),
                 "dbe": rel_err(ben.grad.cpu(), be.grad)}
         G = max(float(v.abs().max()) for v in ref_grads.values())

@@ -249,6 +249,11 @@ def test_native_layer_backward_equals_the_python_launch_sequence(gpu_device, kw,
     results = {}
     try:
         Fn.set_grad_in_place(True)
+        # same kernels on both sides: the native forward would otherwise take the fused edge kernel (a split-operand product
+        # where this small batch's three-launch sequence runs the exact-fp32 MFMA kernel: tests/test_fused_gpu.py) and the
+        # batched weight-only launches, whose gradients re-associate 60-row sums
+        Fn.set_fused_edge(False)
+        Fn.set_batch_weight_only(False)
         for native in (True, False):
             for side in (True, False):
                 torch.manual_seed(0)
@@ -268,6 +273,8 @@ def test_native_layer_backward_equals_the_python_launch_sequence(gpu_device, kw,
     finally:
         Fn.set_grad_in_place(False)
         Fn.set_native_layer_backward(True)
+        Fn.set_fused_edge(True)
+        Fn.set_batch_weight_only(True)
         ops.set_wgrad_side_stream(False)
     ref_loss, ref = results[(False, False)]
     for key, (l, g) in results.items():

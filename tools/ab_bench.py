@@ -37,11 +37,12 @@ VARIANTS = {
     "rows2048": lambda dev: setattr(ops.DegreeClasses, "WGRAD_ROWS", 2048),
     "nobatch": lambda dev: ops.set_wgrad_batching(False),
     "nofused": lambda dev: Fn.set_fused_edge(False),
+    "nobatchwo": lambda dev: Fn.set_batch_weight_only(False),
 }
 
 
 def reset(dev):
-    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True); Fn.set_fused_edge(True)
+    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True); Fn.set_fused_edge(True); Fn.set_batch_weight_only(True)
     ops.set_option(dev, _lib.OPT_STD_BWD_CENTERED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1)
     ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
