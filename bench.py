@@ -170,8 +170,11 @@ def main():
                     help="rehearse launch + barrier + exchange on the CPU (gloo); no kernels, value 0")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the RCCL exchange path even with one rank (rehearsal on a one-GPU box)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="one all-reduce after backward instead of per-layer slices started during backward")
+    ap.add_argument("--overlap", action="store_true",
+                    help="hand every conv layer's slice of the gradient buffer to RCCL during backward (opt-in: the overlapped "
+                         "exchange has never run with more than one RCCL rank -- no multi-GPU box so far; default = ONE "
+                         "all-reduce after backward)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default since round 3; kept for compatibility)")
     args = ap.parse_args()
     if args.graph:
         args.launch = "graph"
@@ -249,7 +252,7 @@ def main():
     # gradient exchange: every conv layer's slice of the flat buffer is handed to RCCL as soon as that layer's
     # weight-gradient launches are issued (overlaps the rest of backward); the remainder follows after backward;
     # finish() waits stream-wise and turns the sum into the average with one gnx_scale launch
-    flat.enable_overlap(not args.no_overlap and args.launch != "graph")
+    flat.enable_overlap(args.overlap and not args.no_overlap and args.launch != "graph")
 
     def eager_step():
         loss = step_body()

@@ -23,6 +23,10 @@
 // half the waves doubled its length.  In-kernel stamps of THIS kernel (tools/ubench/edge_fwd_stamp.hip): issue of the next
 // tile's 25 loads 19 %, MFMAs 15 %, result tile -> LDS 4 %, gather wait + split 11 %, stores + reduction 26 %, barriers 25 %.
 //
+// Also measured and rejected: issuing the next gather right after the image barrier, AHEAD of the reduction's stores (so
+// that it does not queue behind them): 91 vs 99 us without the h1 / m stores, but 121 vs 102 us with them -- the stores then
+// queue behind the gather and the next wait for the gather drains them too.
+//
 // Edge tiles (gnx_edge_tiles): tile j holds every node whose FIRST CSR position lies in [W j, W (j + 1)); with in-degrees
 // <= maxdeg and W = 65 - maxdeg a tile never exceeds 64 message rows.  A violated bound (a degree above the hint) sets
 // sticky range-flag bit 6 and the overflowing rows are dropped (no out-of-bounds access).
@@ -261,9 +265,9 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
     }
   }
   consume_gather(B0, lds);
-  // pipeline state at the top of an iteration (tile t current): image of t in LDS stage cur, gather of tile t + 1 in flight
   load_idx(B1, idx);
-  issue_gather();  // tile 1 (past the end: clamped, harmless loads)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(idx[i][0]), "v"(idx[i][1]), "v"(idx[i][2]));  // arrived before the loop
   __syncthreads();
 
   int cur = 0;
@@ -274,13 +278,16 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
   while (j < g.ntiles) {
     const int j1 = j + tstride;
     const bool has1 = j1 < g.ntiles;
-    // small loads of the next tiles (CSR entry of tile t + 1, indices of tile t + 2): their results are first touched
-    // behind the MFMAs; they queue behind the previous tile's stores, which nobody waits for before then either
+    // loads of the next tiles, oldest first: CSR bounds of tile j1, indices of tile j + 2, then the gather of tile j1 (it
+    // stays in flight under the MFMAs; the two small loads ahead of it are touched right after them)
     const int rpv = load_rp(B1);
     int idn[4][3];
     load_idx(B2, idn);  // (clamped bounds past the end: harmless loads)
+    __builtin_amdgcn_sched_barrier(0);  // keep the small loads AHEAD of the gather in the vmcnt queue
+    issue_gather();  // unconditional (past the end: clamped, harmless loads) so that hipcc can COUNT the loads behind idn
+    const bounds B3 = bounds_at(rel + 3);
     if (tid == 0 && B0.e1 - B0.e0 > EF_BM) atomicOr(g.flag, 64);
-    EF_AT(0);  // issue of the next tiles' loads
+    EF_AT(0);  // issue of the next tile's loads
 
     f32x16 acc, corr;
 #pragma unroll
@@ -304,6 +311,12 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
       }
     }
     EF_AT(1);  // fragment reads + MFMAs
+    // gfx950 counts loads AND stores in one in-order vmcnt: a load result first touched behind the tile's (data-dependent
+    // number of) stores makes hipcc wait vmcnt(0), i.e. for every store of the tile to be acknowledged (measured: 35 % of
+    // the kernel's time).  Everything loaded at the top is touched HERE, where only the gather is outstanding behind it.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(idn[i][0]), "v"(idn[i][1]), "v"(idn[i][2]));
+    asm volatile("" ::"v"(rpv));
     __syncthreads();  // every wave has finished reducing the previous tile out of Cs
     EF_AT(2);
     {
@@ -317,21 +330,6 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
     EF_AT(4);  // wait for the gather, h1, split, LDS stores
     __syncthreads();
     EF_AT(5);
-    // ---- the gather of tile t + 2, issued HERE: the memory pipe has been idle since the previous tile's stores, so it
-    //      leaves at once (issued behind the reduction's ~12 store instructions per wave it queued for 1.8 us = 19 % of
-    //      the kernel), and its latency runs under the reduction below and the next tile's MFMAs.  gfx950 counts loads
-    //      and stores in ONE in-order vmcnt: the next consume_gather waits for "all but the youngest few" operations,
-    //      i.e. also for this tile's stores -- which are a whole MFMA phase old by then.  (Only the gather: its 48
-    //      destination registers are its own; more loads in flight across the reduction made hipcc recycle their
-    //      destinations inside it behind an s_waitcnt vmcnt(0).)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      idx[i][0] = idn[i][0];
-      idx[i][1] = idn[i][1];
-      idx[i][2] = idn[i][2];
-    }
-    issue_gather();
-    EF_AT(0);
 
     // ---- the tile's messages: written once, reduced per destination row in k_pna_agg_fwd's operation order
     {
@@ -410,7 +408,13 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_fwd(edge_fwd_args g) {
     // rotate the pipeline
     B0 = B1;
     B1 = B2;
-    B2 = bounds_at(rel + 3);
+    B2 = B3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      idx[i][0] = idn[i][0];
+      idx[i][1] = idn[i][1];
+      idx[i][2] = idn[i][2];
+    }
     cur ^= 1;
     j = j1;
     if (++rel == 32) {  // refill the bounds vector from the tile that is now current (one full wait per 32 tiles)

@@ -361,6 +361,7 @@ extern "C" int32_t gnx_pna_weight_only_all(gnx_handle* h, int32_t L, const float
   GNX_CHECK_ARG(D <= 0 || weff, "gnx_pna_weight_only_all: weff is NULL");
   const int H = T * F, per = 2 * (pre_layers + post_layers), np = 4 + T * per;
   std::vector<gnx_small_prob> first, second;
+  std::vector<std::vector<gnx_small_prob>> later(T > 2 ? T - 2 : 0);  // bm's towers 2.. : one more launch each
   std::vector<const float*> wsrc;
   std::vector<float*> wdst;
   std::vector<float> wavg;
@@ -383,13 +384,15 @@ extern "C" int32_t gnx_pna_weight_only_all(gnx_handle* h, int32_t L, const float
         first.push_back(sprob(P[2] + t * F, H, P[k], F, nullptr, Wm[l] + t * F, H, H, F, F, 0));
         if (t == 0)
           first.push_back(sprob(P[k + 1], F, P[2], H, P[3], bm[l], H, 1, H, F, GNX_SB_B_TRANS));
-        else  // further towers add on top of the first one's result: atomics, one launch later
-          second.push_back(sprob(P[k + 1], F, P[2] + t * F, H, nullptr, bm[l], H, 1, H, F, GNX_SB_B_TRANS | GNX_SB_ATOMIC));
+        else  // further towers add on top of the previous one's result, one launch later each: a deterministic forward
+          (t == 1 ? second : later[t - 2])
+              .push_back(sprob(P[k + 1], F, P[2] + t * F, H, nullptr, bm[l], H, 1, H, F, GNX_SB_B_TRANS | GNX_SB_ACCUMULATE));
       }
     }
   }
   GNX_TRY(gnx_gemm_small_batched(h, (int32_t)first.size(), first.data()));
   GNX_TRY(gnx_gemm_small_batched(h, (int32_t)second.size(), second.data()));
+  for (auto& v : later) GNX_TRY(gnx_gemm_small_batched(h, (int32_t)v.size(), v.data()));
   if (D > 0)
     GNX_TRY(gnx_pna_weff_batched(h, (int32_t)wsrc.size(), wsrc.data(), 13 * F, F, D, wavg.data(), wdst.data()));
   return GNX_OK;

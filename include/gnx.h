@@ -451,7 +451,7 @@ typedef struct {
   const float* const* dWeff;       /* HOST [L * T]: [D,F,4F] */
 } gnx_pna_finish_args;
 int32_t gnx_pna_stack_finish(gnx_handle* h, const gnx_pna_finish_args* args);
-/* gnx_pna_weight_only for all L layers of a model in 3 launches: avg_deg_log HOST [L]; params HOST [L * np]; EE / Te / Wm /
+/* gnx_pna_weight_only for all L layers of a model in 3 launches (+ 1 per tower beyond the second): avg_deg_log HOST [L]; params HOST [L * np]; EE / Te / Wm /
  * bm HOST [L]; weff HOST [L * T] (D > 0). */
 int32_t gnx_pna_weight_only_all(gnx_handle* h, int32_t L, const float* BE, int32_t R, int32_t T, int32_t F,
                                 int32_t pre_layers, int32_t post_layers, int32_t D, const float* avg_deg_log,

@@ -108,7 +108,7 @@ def test_rccl_exchange_path_with_one_rank(gpu_device):
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for launch, expect in (("eager", "per-layer slices"), ("graph", "one call after backward")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "3",
-                            "--warmup", "2", "--batch", "512", "--no-cpu-baseline", "--launch", launch], env=env,
+                            "--warmup", "2", "--batch", "512", "--no-cpu-baseline", "--launch", launch, "--overlap"], env=env,
                            capture_output=True, text=True, timeout=500)
         assert r.returncode == 0, r.stderr[-3000:]
         out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -1,11 +1,11 @@
 #!/bin/bash
 # fused forward kernel after the load re-ordering (stamps), fused / batched-weight-only tests, same-box A/Bs
 mkdir -p gpurun_out/r3e
-timeout -k 10 120 ./tools/ubench/edge_fwd_stamp_v4 > gpurun_out/r3e/stamp_v4.log 2>&1; cat gpurun_out/r3e/stamp_v4.log
-timeout -k 10 500 python -m pytest tests/test_fused_gpu.py tests/test_model_gpu.py -x -q > gpurun_out/r3e/tests.log 2>&1
+
+timeout -k 10 500 python -m pytest tests/test_fused_gpu.py tests/test_model_gpu.py tests/test_layer_chain_gpu.py tests/test_dropout_gpu.py -q > gpurun_out/r3e/tests.log 2>&1
 echo "rc=$?" >> gpurun_out/r3e/tests.log
 tail -15 gpurun_out/r3e/tests.log
-grep -q "rc=0" gpurun_out/r3e/tests.log || exit 1
+
 timeout -k 10 300 python tools/ab_bench.py --steps 30 --reps 3 base nofused nobatchwo > gpurun_out/r3e/ab.log 2>&1
 cat gpurun_out/r3e/ab.log
 for cus in 128 160 192; do
