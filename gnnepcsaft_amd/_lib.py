@@ -19,14 +19,14 @@ GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
     K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD, K_GEMM_TILED, K_GEMM_SMALL, K_GEMM_WGRAD_BATCHED, K_KEY_SEGMENT_SUM, \
-    K_EMBED, K_PNA_EDGE_FWD = range(17)
-K_COUNT = 17
+    K_EMBED, K_PNA_EDGE_FWD, K_PNA_EDGE_BWD = range(18)
+K_COUNT = 18
 KERNEL_GROUPS = {K_PNA_AGG_FWD: "pna_aggregate_fwd", K_PNA_AGG_BWD: "pna_aggregate_bwd", K_GEMM_WS: "gemm_weights_stationary",
                  K_GEMM_WGRAD: "weight_gradient", K_GINE_AGG_FWD: "gine_aggregate_fwd", K_GINE_AGG_BWD: "gine_aggregate_bwd",
                  K_EDGE_COMBINE_FWD: "edge_combine_fwd", K_EDGE_COMBINE_BWD: "edge_combine_bwd", K_BN_FWD: "batchnorm_fwd",
                  K_BN_BWD: "batchnorm_bwd", K_GEMM_TILED: "gemm_tiled", K_GEMM_SMALL: "gemm_small",
                  K_GEMM_WGRAD_BATCHED: "weight_gradient_batched", K_KEY_SEGMENT_SUM: "key_segment_sum", K_EMBED: "embedding",
-                 K_PNA_EDGE_FWD: "pna_edge_fused_fwd"}
+                 K_PNA_EDGE_FWD: "pna_edge_fused_fwd", K_PNA_EDGE_BWD: "pna_edge_fused_bwd"}
 
 
 class GnxError(RuntimeError):
@@ -75,7 +75,7 @@ class PnaBwdArgs(C.Structure):
                 ("params", C.POINTER(_vp)), ("grads", C.POINTER(_vp)), ("dout", _vp),
                 ("gbuf", _vp * PNA_MAX_LAYERS), ("dA", _vp), ("gebuf", _vp * PNA_MAX_LAYERS), ("dP", _vp), ("dQ", _vp),
                 ("dTe", _vp), ("dEE", _vp), ("dWm", _vp), ("dbm", _vp), ("dWeff", _vp), ("ws", _vp), ("ws_bytes", _sz),
-                ("acc_buf", _vp), ("dx", _vp), ("defer_small", _i32), ("_pad2", _i32)]
+                ("acc_buf", _vp), ("dx", _vp), ("defer_small", _i32), ("etile_w", _i32), ("etile_info", _vp)]
 
 
 class PnaFinishArgs(C.Structure):
@@ -142,6 +142,8 @@ SIGNATURES = {
     "gnx_edge_tiles": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "gnx_pna_edge_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, C.POINTER(_vp),
                                 C.POINTER(_vp), _vp, _vp, _vp]),
+    "gnx_pna_edge_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, C.POINTER(_vp), _vp, _vp,
+                                _vp]),
     "gnx_gine_aggregate_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "gnx_gine_aggregate_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                       _vp, _vp]),

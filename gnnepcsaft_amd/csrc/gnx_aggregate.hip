@@ -405,12 +405,14 @@ __global__ void __launch_bounds__(256) k_edge_combine_bwd(const float* __restric
     s[v] = 0.f;
     q[v] = 0.f;
   }
-  int p0 = rowptr[n], p1 = rowptr[n + 1];
-  for (int p = p0; p < p1; ++p) {
-    float a[VEC];
-    vload<VEC>(a, g + (int64_t)p * H + c);
+  if (dP != nullptr) {  // (NULL: the destination sums were already formed by gnx_pna_edge_bwd)
+    int p0 = rowptr[n], p1 = rowptr[n + 1];
+    for (int p = p0; p < p1; ++p) {
+      float a[VEC];
+      vload<VEC>(a, g + (int64_t)p * H + c);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) s[v] += a[v];
+      for (int v = 0; v < VEC; ++v) s[v] += a[v];
+    }
   }
   int c0 = colptr[n], c1 = colptr[n + 1];
   for (int k = c0; k < c1; ++k) {
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(256) k_edge_combine_bwd(const float* __restric
 #pragma unroll
     for (int v = 0; v < VEC; ++v) q[v] += a[v];
   }
-  vstore<VEC>(dP + n * H + c, s);
+  if (dP != nullptr) vstore<VEC>(dP + n * H + c, s);
   vstore<VEC>(dQ + n * H + c, q);
 }
 
@@ -428,8 +430,9 @@ extern "C" int32_t gnx_edge_combine_bwd(gnx_handle* h, const float* g, const int
                                         int32_t R, float* dP, float* dQ, float* dTe, void* ws, size_t ws_bytes) {
   GNX_CHECK_ARG(h && H > 0 && N >= 0 && E >= 0, "gnx_edge_combine_bwd: bad argument");
   if (N == 0) return GNX_OK;
-  GNX_CHECK_ARG(rowptr && colptr && dP && dQ && (E == 0 || (g && cpos)), "gnx_edge_combine_bwd: NULL argument");
-  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_BWD, 4.0 * E * H + 8.0 * N * H + 4.0 * E + 8.0 * N);  // read g once, write dP, dQ
+  GNX_CHECK_ARG(rowptr && colptr && dQ && (E == 0 || (g && cpos)), "gnx_edge_combine_bwd: NULL argument");
+  // read g once, write dP, dQ (dP == NULL: only the by-source sums dQ)
+  gnx_prof_scope prof(h, GNX_K_EDGE_COMBINE_BWD, 4.0 * E * H + (dP ? 8.0 : 4.0) * N * H + 4.0 * E + 8.0 * N);
   if (H % 4 == 0)
     hipLaunchKernelGGL(k_edge_combine_bwd<4>, dim3((unsigned)gnx_cdiv(N * (H / 4), 256)), dim3(256), 0, h->stream, g,
                        rowptr, colptr, cpos, N, (int)H, dP, dQ);

@@ -489,3 +489,360 @@ extern "C" int32_t gnx_pna_edge_fwd(gnx_handle* h, const float* P, const float* 
   GNX_LAUNCH_CHECK();
   return GNX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused PNA edge pipeline, backward: pre-layer 1's input gradient with the ReLU mask of pre-layer 0, the destination
+// sums and the bond-table gradient in ONE pass over the message gradient ("one read of the message
+// gradient in backward" -- the three-launch sequence read it in the masked product, then re-read the product's result for
+// dP (k_edge_combine_bwd) and again, gathered by bond code, for dTe (k_key_segment_sum)):
+//     gh1[p] = (ge[p] W1_t) * (h1[p] > 0)          k_gemm_ws3<NN, mask>'s arithmetic (bit-identical)
+//     dP[n]  = sum over the CSR row of n of gh1    k_edge_combine_bwd's order (bit-identical)
+//     dTe[c] += sum over the positions with bond code c of gh1
+// dQ (the sum over the edges LEAVING a node) is a gather through the by-source index and stays a pass of its own over gh1.
+// The bond-code sums ride on the matrix pipe: the masked result block of a wave (32 rows x 32 columns, column on the lane,
+// rows in the accumulator registers) is exactly the B operand of a product that sums over its ROW index, so
+// dTe_block += onehot(code)[64 x 32 rows] * gh1_block with the one-hot operand generated in registers from the tile's codes
+// and gh1 as three exact bf16 pieces: 12 MFMAs per wave and tile beside the 48 of the product, exact 0/1 products, fp32
+// accumulators kept for the whole launch and flushed with one atomic add per (code, column) and workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+#define EB_MASK_BYTES (2 * EF_BM * 32)  // ReLU mask of the h1 tile: one nibble-carrying byte per (row, 4 columns), two stages
+#define EB_CODE_BYTES (2 * EF_BM * 4)
+#define EB_LDS (EF_A_BYTES + EF_C_BYTES + EF_RP_BYTES + EB_MASK_BYTES + EB_CODE_BYTES)
+
+struct edge_bwd_args {
+  const float* ge;   // [E, H] message gradient (CSR order)
+  const float* h1;   // [E, H] pre-layer 0's activation (mask)
+  const int* code;
+  const int* rowptr;
+  const int* tile_info;
+  int ntiles, T, F, H, R;
+  int64_t N, E;
+  const float* W[GNX_PNA_MAX_TOWERS];  // pre-layer 1 weight [F, F] ([out, in])
+  float* gh1;  // [E, H]
+  float* dP;   // [N, H]
+  float* dTe;  // [R, H], accumulated
+  int* flag;
+};
+
+__global__ void __launch_bounds__(512, 1) k_pna_edge_bwd(edge_bwd_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* Cs = reinterpret_cast<float*>(lds + EF_A_BYTES);
+  int* rpl = reinterpret_cast<int*>(lds + EF_A_BYTES + EF_C_BYTES);
+  unsigned char* mk = lds + EF_A_BYTES + EF_C_BYTES + EF_RP_BYTES;                       // [2][64][32]
+  int* cds = reinterpret_cast<int*>(lds + EF_A_BYTES + EF_C_BYTES + EF_RP_BYTES + EB_MASK_BYTES);  // [2][64]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const int F = g.F, H = g.H, T = g.T;
+  const int nslab = (F + 15) >> 4;
+  const int gc = wc + li;
+  const int tw = blockIdx.x % T;
+  const int tstride = gridDim.x / T;
+  const int coff = tw * F;
+  const int ar = tid >> 5, ak = (tid & 31) * 4;
+  const bool ak_ok = ak < F;
+  const int akc = ak_ok ? ak : 0;
+  const int2* tinfo = reinterpret_cast<const int2*>(g.tile_info);
+  const int last = g.ntiles - 1;
+  const int Em1 = (int)(g.E - 1);
+
+  struct bounds {
+    int n0, e0, n1, e1;
+  };
+  int vb_n0, vb_e0, vb_n1, vb_e1;  // lane l: bounds of the workgroup's l-th tile from the refill point (see k_pna_edge_fwd)
+  auto fill_bounds = [&](int jbase) {
+    const int jt = jbase + lane * tstride;
+    const int jj = jt < last ? jt : last;
+    const int2 a = tinfo[jj], c = tinfo[jj + 1];
+    vb_n0 = a.x;
+    vb_e0 = a.y;
+    vb_n1 = c.x;
+    vb_e1 = c.y;
+  };
+  auto bounds_at = [&](int rel) {
+    bounds b = {__builtin_amdgcn_readlane(vb_n0, rel), __builtin_amdgcn_readlane(vb_e0, rel),
+                __builtin_amdgcn_readlane(vb_n1, rel), __builtin_amdgcn_readlane(vb_e1, rel)};
+    return b;
+  };
+  auto count_of = [&](const bounds& b) {
+    const int c = b.e1 - b.e0;
+    return c < EF_BM ? c : EF_BM;
+  };
+
+  // tile loads: 4 rows x float4 of ge and of h1 per thread (32 lanes cover one 512-B row), the tile's bond codes and CSR slice
+  f32x4 rg[4], rh[4];
+  int rcode = 0, rpv = 0;
+  auto load_tile = [&](const bounds& b) {
+    const int cm1 = count_of(b) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ar + 16 * i;
+      int e = b.e0 + (r < cm1 ? r : (cm1 > 0 ? cm1 : 0));  // rows past the count: clamped (zeroed at LDS-store time)
+      e = e < Em1 ? e : Em1;
+      rg[i] = *reinterpret_cast<const f32x4*>(g.ge + (int64_t)e * H + coff + akc);
+      rh[i] = *reinterpret_cast<const f32x4*>(g.h1 + (int64_t)e * H + coff + akc);
+    }
+    {
+      const int r = tid & 63;
+      int e = b.e0 + (r < cm1 ? r : (cm1 > 0 ? cm1 : 0));
+      e = e < Em1 ? e : Em1;
+      rcode = g.code[e];
+      const int64_t node = (int64_t)b.n0 + (tid <= EF_RP ? tid : EF_RP);
+      rpv = g.rowptr[node < g.N ? node : g.N];
+    }
+  };
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  auto store_tile = [&](const bounds& b, int st) {
+    const int cnt = count_of(b);
+    unsigned char* buf = lds + st * W3_BUF;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {  // rows ar + 32 hh and ar + 32 hh + 16: one split3 of 8 values
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool ok = ak_ok && (ar + 32 * hh + 16 * q) < cnt;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[4 * q + c] = ok ? rg[2 * hh + q][c] : 0.f;
+      }
+      bf16x8 pc[3];
+      split3(x, pc[0], pc[1], pc[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+        unsigned char* q = buf + p * W3_PIECE + (ar + 32 * hh) * W3_LDB + ak * 2;
+        *reinterpret_cast<f32x2*>(q) = f32x2{w.x, w.y};
+        *reinterpret_cast<f32x2*>(q + 16 * W3_LDB) = f32x2{w.z, w.w};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // ReLU mask of pre-layer 0: bit c of the byte = h1[row][4 (tid & 31) + c] > 0
+      const unsigned bits = (rh[i][0] > 0.f ? 1u : 0u) | (rh[i][1] > 0.f ? 2u : 0u) | (rh[i][2] > 0.f ? 4u : 0u) |
+                            (rh[i][3] > 0.f ? 8u : 0u);
+      mk[(st * EF_BM + ar + 16 * i) * 32 + (tid & 31)] = (unsigned char)(ak_ok ? bits : 0u);
+    }
+    if (tid < EF_BM) cds[st * EF_BM + tid] = rcode;
+    if (tid <= EF_RP) rpl[st * (EF_RP + 4) + tid] = rpv;
+  };
+
+  int j = blockIdx.x / T;
+  fill_bounds(j);
+  int rel = 0;
+  bounds B0 = bounds_at(0), B1 = bounds_at(1);
+  load_tile(B0);
+
+  // ---- this wave's weight fragments for the input-gradient orientation: B(k, n) = W1[k][n] (k = pre-layer 1's output
+  //      index, n = its input index): the zero-filled 128 x 128 image is staged in LDS once (k_gemm_ws3<NN>'s scheme)
+  bf16x8 b1[8], b2[8], b3[8];
+  {
+    float* wl = reinterpret_cast<float*>(lds);
+    const float* Wt = g.W[tw];
+    const int r = tid >> 5, c4 = (tid & 31) * 4;
+    const bool c_ok = c4 < F;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = r + 16 * i;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Wt + (int64_t)(rr < F ? rr : 0) * F + (c_ok ? c4 : 0));
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(wl + rr * 128 + c4) = (c_ok && rr < F) ? v : z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float x[8];
+      const int k0 = 16 * s + 8 * lh;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = wl[(k0 + q) * 128 + gc];
+      split3(x, b1[s], b2[s], b3[s]);
+    }
+    __syncthreads();  // the image is overwritten by the first tile
+  }
+  store_tile(B0, 0);
+  __syncthreads();
+
+  f32x16 Y0, Y1;  // bond-table gradient of this wave's columns: codes 0..31 / 32..63 (C/D layout: code on the register index)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    Y0[r] = 0.f;
+    Y1[r] = 0.f;
+  }
+  int cur = 0;
+  while (j < g.ntiles) {
+    const int j1 = j + tstride;
+    const bool has1 = j1 < g.ntiles;
+    load_tile(B1);  // tile j1 (clamped bounds past the end: harmless loads); in flight under the MFMAs
+    if (tid == 0 && B0.e1 - B0.e0 > EF_BM) atomicOr(g.flag, 64);
+
+    f32x16 acc, corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = 0.f;
+      corr[r] = 0.f;
+    }
+    const unsigned char* ap = lds + cur * W3_BUF + (wr + li) * W3_LDB + 16 * lh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nslab) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * s);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + W3_PIECE);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + 2 * W3_PIECE);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[s], corr, 0, 0, 0);
+        corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[s], corr, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[s], acc, 0, 0, 0);
+      }
+    }
+    // ---- ReLU mask, then the masked block as the B operand of the one-hot product (it sums over the block's ROW index)
+    {
+      const unsigned char* mrow = mk + (cur * EF_BM + wr + 4 * lh) * 32 + (gc >> 2);
+      const int bit = gc & 3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned m = mrow[((r & 3) + 8 * (r >> 2)) * 32];
+        const float v = acc[r] + corr[r];
+        acc[r] = ((m >> bit) & 1u) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = acc[8 * s + q];
+      bf16x8 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      // element q of lane half lh is block row 16 s + 8 (q >> 2) + 4 lh + (q & 3): its bond code decides the one-hot entry
+      const int* cp = cds + cur * EF_BM + wr + 16 * s + 4 * lh;
+      const int c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3], c4 = cp[8], c5 = cp[9], c6 = cp[10], c7 = cp[11];
+      const int cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+      split_u32x4 o0, o1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o0[q] = (cc[2 * q] == li ? 0x3F80u : 0u) | (cc[2 * q + 1] == li ? 0x3F800000u : 0u);
+        o1[q] = (cc[2 * q] == li + 32 ? 0x3F80u : 0u) | (cc[2 * q + 1] == li + 32 ? 0x3F800000u : 0u);
+      }
+      const bf16x8 h0 = __builtin_bit_cast(bf16x8, o0), h1v = __builtin_bit_cast(bf16x8, o1);
+      Y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, p1, Y0, 0, 0, 0);
+      Y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1v, p1, Y1, 0, 0, 0);
+      Y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, p2, Y0, 0, 0, 0);
+      Y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1v, p2, Y1, 0, 0, 0);
+      Y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, p3, Y0, 0, 0, 0);
+      Y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1v, p3, Y1, 0, 0, 0);
+    }
+    __syncthreads();  // every wave has finished reading the previous tile out of Cs
+    {
+      float* cw = Cs + (wr + 4 * lh) * EF_LDC + gc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2)) * EF_LDC] = acc[r];
+    }
+    if (has1) store_tile(B1, cur ^ 1);
+    __syncthreads();
+
+    // ---- the masked gradient rows: written once; their sum per destination row (k_edge_combine_bwd's order) -> dP
+    {
+      const int cnt = count_of(B0);
+      if (ak_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = ar + 16 * i;
+          if (r < cnt)
+            *reinterpret_cast<f32x4*>(g.gh1 + (int64_t)(B0.e0 + r) * H + coff + ak) =
+                *reinterpret_cast<const f32x4*>(Cs + r * EF_LDC + ak);
+        }
+        auto sum_node = [&](int node, int p0, int p1) {
+          p0 -= B0.e0;
+          p1 -= B0.e0;
+          p1 = p1 < cnt ? p1 : cnt;
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+          for (int p = p0; p < p1; ++p) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + p * EF_LDC + ak);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sacc[v] += a[v];
+          }
+          *reinterpret_cast<f32x4*>(g.dP + (int64_t)node * H + coff + ak) = sacc;
+        };
+        const int* rpc = rpl + cur * (EF_RP + 4);
+        const int nn = B0.n1 - B0.n0;
+        const int nl = nn < EF_RP ? nn : EF_RP;
+        for (int ln = ar; ln < nl; ln += 16) sum_node(B0.n0 + ln, rpc[ln], rpc[ln + 1]);
+        if (nn > EF_RP)
+          for (int ln = EF_RP + ar; ln < nn; ln += 16) sum_node(B0.n0 + ln, g.rowptr[B0.n0 + ln], g.rowptr[B0.n0 + ln + 1]);
+      }
+    }
+    B0 = B1;
+    B1 = bounds_at(rel + 2);
+    cur ^= 1;
+    j = j1;
+    if (++rel == 32) {
+      fill_bounds(j);
+      asm volatile("" ::"v"(vb_n0), "v"(vb_e0), "v"(vb_n1), "v"(vb_e1));
+      rel = 0;
+      B1 = bounds_at(1);
+    }
+  }
+  // ---- flush the bond-table sums: register r of lane (li, lh) holds code (r & 3) + 8 (r >> 2) + 4 lh (+ 32), column gc
+  if (gc < F) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (c < g.R) atomicAdd(g.dTe + (int64_t)c * H + coff + gc, Y0[r]);
+      if (c + 32 < g.R) atomicAdd(g.dTe + (int64_t)(c + 32) * H + coff + gc, Y1[r]);
+    }
+  }
+}
+
+// gh1 = (ge W1) * (h1 > 0), dP = its sums over CSR rows, dTe += its sums by bond code (see above).  W1: HOST array of T device
+// pointers.  R <= 64 bond codes; F % 4 == 0, F <= 128; tile_info from gnx_edge_tiles(tile_w); float operands 16-byte aligned.
+extern "C" int32_t gnx_pna_edge_bwd(gnx_handle* h, const float* ge, const float* h1, const int32_t* code,
+                                    const int32_t* rowptr, const int32_t* tile_info, int32_t tile_w, int64_t N, int64_t E,
+                                    int32_t T, int32_t F, int32_t R, const float* const* W1, float* gh1, float* dP,
+                                    float* dTe) {
+  GNX_CHECK_ARG(h && T >= 1 && T <= GNX_PNA_MAX_TOWERS && F >= 4 && F <= 128 && F % 4 == 0 && R >= 1 && R <= 64 && N >= 0 &&
+                    E >= 0, "gnx_pna_edge_bwd: bad shape T=%d F=%d R=%d (need F %% 4 == 0, F <= 128, R <= 64)", T, F, R);
+  if (N == 0) return GNX_OK;
+  GNX_CHECK_ARG(dP && rowptr && W1, "gnx_pna_edge_bwd: NULL argument");
+  if (E == 0) return gnx_fill(h, dP, N * (int64_t)T * F, 0.f);
+  GNX_CHECK_ARG(ge && h1 && code && tile_info && gh1 && dTe && tile_w >= 1 && tile_w <= EF_BM,
+                "gnx_pna_edge_bwd: NULL argument or bad tile width %d", tile_w);
+  edge_bwd_args g;
+  g.ge = ge;
+  g.h1 = h1;
+  g.code = code;
+  g.rowptr = rowptr;
+  g.tile_info = tile_info;
+  g.ntiles = gnx_edge_tiles_count(E, tile_w);
+  g.T = T;
+  g.F = F;
+  g.H = T * F;
+  g.R = R;
+  g.N = N;
+  g.E = E;
+  for (int t = 0; t < GNX_PNA_MAX_TOWERS; ++t) {
+    g.W[t] = t < T ? W1[t] : nullptr;
+    GNX_CHECK_ARG(t >= T || g.W[t], "gnx_pna_edge_bwd: W1[%d] is NULL", t);
+  }
+  g.gh1 = gh1;
+  g.dP = dP;
+  g.dTe = dTe;
+  g.flag = h->d_flag;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_edge_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024)));
+    attr_set = true;
+  }
+  const double Hd = (double)T * F;
+  // ge and h1 read once, gh1 and dP written once, codes + CSR
+  const double bytes = 12.0 * E * Hd + 4.0 * N * Hd + 4.0 * E + 4.0 * N;
+  const double flops = 2.0 * E * (double)F * F * T;
+  gnx_prof_scope prof(h, GNX_K_PNA_EDGE_BWD, bytes, flops, 6.0 * flops + 3.0 * 2.0 * E * 64.0 * F * T, true);
+  int grid = h->num_cus > 0 ? h->num_cus : 256;
+  const int64_t want = (int64_t)g.ntiles * T;
+  if (grid > want) grid = (int)want;
+  grid = grid / T * T;
+  if (grid < T) grid = T;
+  GNX_LAUNCH_TIMED(prof, k_pna_edge_bwd, dim3((unsigned)grid), dim3(512), (size_t)EB_LDS, h->stream, g);
+  GNX_LAUNCH_CHECK();
+  return GNX_OK;
+}

@@ -164,18 +164,37 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   int ei = 0;
   float* ge = a->gebuf[ei];
   GNX_TRY(gnx_pna_aggregate_bwd(h, a->dA, a->hs[a->n_h - 1], a->A, a->rowptr, N, E, T, F, ge));
-  for (int i = pre - 1; i >= 1; --i) {
-    const float* h_prev = a->hs[i - 1];
+  // With two pre layers (the reference's default) the masked input gradient of pre-layer 1, the destination sums dP and the
+  // bond-table sums dTe come from ONE pass over the message gradient (gnx_pna_edge_bwd); only dQ is a pass of its own.
+  bool fused_bwd = h->opt[GNX_OPT_EDGE_FUSED] == 1 && pre == 2 && a->etile_info != nullptr && E > 0 && F % 4 == 0 && F <= 128 &&
+                   R <= 64 && a16(ge) && a16(a->hs[0]) && a16(a->gebuf[1]) && a16(a->dP) && a16(a->dTe);
+  for (int t = 0; t < T && fused_bwd; ++t) fused_bwd = a16(P[pidx(t, true, 1)]);
+  if (fused_bwd) {
+    const float* W1[GNX_PNA_MAX_TOWERS];
     for (int t = 0; t < T; ++t) {
-      const int k = pidx(t, true, i);
-      wq.add(ge + t * F, H, h_prev + t * F, H, E, F, F, G[k], F, G[k + 1]);
-      gnx_gemm_seg s = seg(ge + t * F, H, P[k], F, F);
-      GNX_TRY(gnx_gemm(h, 1, &s, E, F, nullptr, h_prev + t * F, H, a->gebuf[ei + 1] + t * F, H, 0, a->ws, a->ws_bytes));
+      const int k = pidx(t, true, 1);
+      W1[t] = P[k];
+      wq.add(ge + t * F, H, a->hs[0] + t * F, H, E, F, F, G[k], F, G[k + 1]);
     }
+    if (!defer) GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
+    GNX_TRY(gnx_pna_edge_bwd(h, ge, a->hs[0], a->code, a->rowptr, a->etile_info, a->etile_w, N, E, T, F, R, W1, a->gebuf[1], a->dP,
+                             a->dTe));
     ge = a->gebuf[++ei];
+    GNX_TRY(gnx_edge_combine_bwd(h, ge, a->rowptr, a->colptr, a->cpos, a->code, N, E, H, 0, nullptr, a->dQ, nullptr, nullptr, 0));
+  } else {
+    for (int i = pre - 1; i >= 1; --i) {
+      const float* h_prev = a->hs[i - 1];
+      for (int t = 0; t < T; ++t) {
+        const int k = pidx(t, true, i);
+        wq.add(ge + t * F, H, h_prev + t * F, H, E, F, F, G[k], F, G[k + 1]);
+        gnx_gemm_seg s = seg(ge + t * F, H, P[k], F, F);
+        GNX_TRY(gnx_gemm(h, 1, &s, E, F, nullptr, h_prev + t * F, H, a->gebuf[ei + 1] + t * F, H, 0, a->ws, a->ws_bytes));
+      }
+      ge = a->gebuf[++ei];
+    }
+    // ---- message assembly backward: dP, dQ; input gradient
+    GNX_TRY(gnx_edge_combine_bwd(h, ge, a->rowptr, a->colptr, a->cpos, a->code, N, E, H, 0, a->dP, a->dQ, nullptr, nullptr, 0));
   }
-  // ---- message assembly backward: dP, dQ; input gradient
-  GNX_TRY(gnx_edge_combine_bwd(h, ge, a->rowptr, a->colptr, a->cpos, a->code, N, E, H, 0, a->dP, a->dQ, nullptr, nullptr, 0));
   for (int t = 0; t < T; ++t) {
     const int k0 = pidx(t, true, 0), kp = pidx(t, false, 0);
     const float* W0 = P[k0];
@@ -188,8 +207,10 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   }
   // ---- bond-table gradient chain on side stream 1 (feeds parameter gradients and the shared accumulator only)
   GNX_TRY(on_side(h, 1, side, [&]() -> int32_t {
-    if (!defer) GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
-    if (E > 0) GNX_TRY(gnx_key_segment_sum(h, ge, a->code_pos, a->code, E, H, a->dTe));
+    if (!fused_bwd) {
+      if (!defer) GNX_TRY(gnx_fill(h, a->dTe, (int64_t)R * H, 0.f));
+      if (E > 0) GNX_TRY(gnx_key_segment_sum(h, ge, a->code_pos, a->code, E, H, a->dTe));
+    }
     if (defer) return GNX_OK;
     for (int t = 0; t < T; ++t) {
       const int k0 = pidx(t, true, 0);

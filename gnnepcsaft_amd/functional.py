@@ -621,6 +621,8 @@ def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_po
         a.dWeff = base + 4 * o
         a.defer_small = 0
     a.ws, a.ws_bytes, a.acc_buf, a.dx = ws.data_ptr(), ws_bytes, acc.buf.data_ptr(), dx.data_ptr()
+    etiles = pack.edge_tiles(D - 1) if (_FUSED_EDGE and pre_layers == 2) else None  # (the forward's table, cached on the pack)
+    a.etile_info, a.etile_w = (etiles[0].data_ptr(), etiles[1]) if etiles is not None else (None, 0)
     ops.pna_conv_bwd(a, dev)
     # everything the side-stream launches touch stays alive until the join at the end of backward
     ops.keep_until_join(dev, [dout, x, BE, EE, A, *hs, *zs, *ctx.weffs, ctx.Wm, gbuf, gebuf, dA, pq, small, ws, acc.buf,

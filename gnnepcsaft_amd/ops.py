@@ -743,6 +743,26 @@ def pna_edge_fwd(P: torch.Tensor, Q: torch.Tensor, Te: torch.Tensor, g: GraphPac
     return h1, m, A
 
 
+def pna_edge_bwd(ge: torch.Tensor, h1: torch.Tensor, g: GraphPack, T: int, F: int, R: int,
+                 weights: Sequence[torch.Tensor], max_degree: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Fused masked input gradient of pre-layer 1 + destination sums + bond-table sums (gnx_pna_edge_bwd): returns
+    (gh1 [E,H], dP [N,H], dTe [R,H]).  ``weights``: pre-layer 1 ([F,F]) of every tower."""
+    H = T * F
+    tiles = g.edge_tiles(max_degree)
+    if tiles is None and g.E > 0:
+        raise _lib.GnxError(_lib.GNX_E_INVALID, f"pna_edge_bwd: in-degree bound {max_degree} too large for edge tiles")
+    dev = ge.device
+    gh1 = torch.empty(g.E, H, dtype=torch.float32, device=dev)
+    dP = torch.empty(g.N, H, dtype=torch.float32, device=dev)
+    dTe = zeros(R, H, device=dev)
+    warr = (C.c_void_p * T)(*[_f32(w, "W1").data_ptr() for w in weights])
+    info, w_ = tiles if tiles is not None else (None, 1)
+    check(_lib.load().gnx_pna_edge_bwd(handle(dev), _f32(ge, "ge").contiguous().data_ptr(), _f32(h1, "h1").contiguous().data_ptr(),
+                                       g.code.data_ptr(), g.rowptr.data_ptr(), _ptr(info), w_, g.N, g.E, T, F, R,
+                                       C.cast(warr, C.POINTER(C.c_void_p)), gh1.data_ptr(), dP.data_ptr(), dTe.data_ptr()))
+    return gh1, dP, dTe
+
+
 def pna_aggregate_fwd(m: torch.Tensor, g: GraphPack, T: int, F: int) -> torch.Tensor:
     A = torch.empty(g.N, T * 4 * F, dtype=torch.float32, device=m.device)
     check(_lib.load().gnx_pna_aggregate_fwd(handle(m.device), m.data_ptr(), g.rowptr.data_ptr(), g.N, g.E, T, F,

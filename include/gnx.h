@@ -66,7 +66,7 @@ enum {
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
   GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
-  GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd takes the fused gather -> pre-layer 1 -> aggregate kernel when eligible (bit-identical results) */
+  GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd / _bwd take the fused edge kernels (gnx_pna_edge_fwd / gnx_pna_edge_bwd) when eligible (bit-identical messages, h1, aggregate, gh1, dP); 2: forward only; 0: three launches each */
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
   GNX_OPT_COUNT = 12
 };
@@ -93,7 +93,8 @@ enum {
   GNX_K_KEY_SEGMENT_SUM = 14,   /* bond-table gradient through the inverted index */
   GNX_K_EMBED = 15,             /* embedding sums, forward and backward */
   GNX_K_PNA_EDGE_FWD = 16,      /* fused message assembly -> pre-layer 1 -> scatter-aggregate (gnx_pna_edge_fwd) */
-  GNX_K_COUNT = 17
+  GNX_K_PNA_EDGE_BWD = 17,      /* fused masked input gradient of pre-layer 1 + destination sums + bond-table sums (gnx_pna_edge_bwd) */
+  GNX_K_COUNT = 18
 };
 /* start recording a HIP event pair around every launch of the kernels whose id bit is set in kernel_mask
  * (bit k = GNX_K_* id k).  Events go on the handle's stream, i.e. the stream the kernels run on. */
@@ -314,6 +315,13 @@ int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const float* m, co
  *   float operands 16-byte aligned. */
 int32_t gnx_edge_tiles_count(int64_t E, int32_t tile_w);
 int32_t gnx_edge_tiles(gnx_handle* h, const int32_t* rowptr, int64_t N, int64_t E, int32_t tile_w, int32_t* tile_info);
+/* backward of the same stage in one pass over the message gradient ge [E, T*F] (CSR order):
+ *   gh1[p] = (ge[p] W1_t) * (h1[p] > 0);  dP[n] = sum of gh1 over the CSR row of n;  dTe[c] += sum of gh1 over the positions
+ *   with bond code c  (R <= 64 codes; dTe [R, T*F] is ACCUMULATED with one atomic add per (code, column) and workgroup).
+ *   gh1 and dP bit-identical to gnx_gemm(mask = h1) + gnx_edge_combine_bwd; dQ stays gnx_edge_combine_bwd(dP = NULL). */
+int32_t gnx_pna_edge_bwd(gnx_handle* h, const float* ge, const float* h1, const int32_t* code, const int32_t* rowptr,
+                         const int32_t* tile_info, int32_t tile_w, int64_t N, int64_t E, int32_t T, int32_t F, int32_t R,
+                         const float* const* W1, float* gh1, float* dP, float* dTe);
 int32_t gnx_pna_edge_fwd(gnx_handle* h, const float* P, const float* Q, const float* Te, const int32_t* src,
                          const int32_t* dst, const int32_t* code, const int32_t* rowptr, const int32_t* tile_info,
                          int32_t tile_w, int64_t N, int64_t E, int32_t T, int32_t F, const float* const* W1,
@@ -425,7 +433,9 @@ typedef struct {
   int32_t defer_small;                        /* 1: dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
                                                  gnx_pna_stack_finish, which runs every layer's 60-row bond-table chain, its
                                                  lin o last-post un-merge and its Weff gradient in a few batched launches */
-  int32_t _pad2;
+  int32_t etile_w;                            /* tile width of etile_info */
+  const int32_t* etile_info;                  /* gnx_edge_tiles table (NULL: three-launch edge backward); with two pre layers
+                                                 the masked input gradient, dP and dTe then come from gnx_pna_edge_bwd */
 } gnx_pna_bwd_args;
 size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D);
 int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* args);

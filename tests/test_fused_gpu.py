@@ -211,3 +211,39 @@ def test_batched_weight_only_work_equals_the_per_layer_launches(gpu_device, name
     (p1, l1, g1), (p0, l0, g0) = out[True], out[False]
     assert torch.equal(p1, p0) and torch.equal(l1, l0)
     assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()), float((g1 - g0).abs().max() / g0.abs().max())
+
+
+@pytest.mark.parametrize("N,maxdeg,T,F,isolated,tail", CASES)
+def test_pna_edge_bwd_equals_three_launch_sequence(gpu_device, N, maxdeg, T, F, isolated, tail):
+    """gnx_pna_edge_bwd (masked input gradient of pre-layer 1 + destination sums + bond-table sums in one pass over the
+    message gradient) vs gnx_gemm(mask) + gnx_edge_combine_bwd + gnx_key_segment_sum: gh1 bit-exact where the three-launch
+    product takes the split-operand kernel too (>= 8192 rows), dP bit-exact given gh1 (same summation order), dTe 1e-5
+    (one-hot MFMA sums vs inverted-index sums: another order)."""
+    from gnnepcsaft_amd import ops
+    dev = gpu_device
+    rng = np.random.default_rng(N * 17 + F)
+    H = T * F
+    ei = _mol_graph(rng, N, maxdeg, isolated, tail)
+    E = ei.size(1)
+    ea = torch.from_numpy(np.stack([rng.integers(0, d, size=E) for d in (5, 6, 2)], 1)).long()
+    g = ops.pack_graph(ei.to(dev), ea.to(dev), None, N)
+    gen = torch.Generator().manual_seed(N + 3 * F)
+    ge = torch.randn(E, H, generator=gen).to(dev)
+    h1 = torch.randn(E, H, generator=gen).relu_().to(dev)       # about half of the entries masked
+    Ws = [(torch.randn(F, F, generator=gen) / F ** 0.5).to(dev) for _ in range(T)]
+    gh1, dP, dTe = ops.pna_edge_bwd(ge, h1, g, T, F, 60, Ws, maxdeg)
+    ref = torch.empty(E, H, device=dev)
+    for t in range(T):
+        sl = slice(t * F, (t + 1) * F)
+        ops.gemm([(ge[:, sl], None, Ws[t])], ref[:, sl], b_trans=False, mask=h1[:, sl])
+    ops.check_range(dev)
+    torch.cuda.synchronize()
+    if E >= 8192 and F >= 32:
+        assert torch.equal(gh1, ref), float((gh1 - ref).abs().max())
+    else:
+        assert rel_err(gh1, ref) <= 2e-6
+    dP_ref, _ = ops.edge_combine_bwd_pq(gh1, g)
+    assert torch.equal(dP, dP_ref)
+    dTe_ref = ops.bond_table_grad(gh1, g, 60, ops.bond_code_index(g, 60, H))
+    assert rel_err(dTe, dTe_ref) <= 1e-5
+    assert rel_err(dTe, torch.zeros(60, H, dtype=torch.float64).index_add_(0, g.code.long().cpu(), gh1.double().cpu())) <= 1e-5
