@@ -180,16 +180,24 @@ class InferenceEngine:
             xt = x[:, t * F:(t + 1) * F]
             ops.gemm([(xt, None, lay["Wi"][t])], P[:, t * F:(t + 1) * F])
             ops.gemm([(xt, None, lay["Wj"][t])], Q[:, t * F:(t + 1) * F])
-        h = ops.edge_combine_fwd(P, Q, lay["Te"], pack, relu=lay["pre_layers"] > 1)
-        for i in range(lay["pre_layers"] - 1):
-            hn = torch.empty(pack.E, H, device=dev)
-            for t in range(T):
-                w, b = lay["pre"][t][i]
-                ops.gemm([(h[:, t * F:(t + 1) * F], None, w)], hn[:, t * F:(t + 1) * F], bias=b,
-                         relu=i < lay["pre_layers"] - 2)
-            h = hn
-        A = ops.pna_aggregate_fwd(h, pack, T, F)
         dc = pack.degree_classes(self.max_degree)
+        tiles = pack.edge_tiles(dc.D - 1) if (dc is not None and lay["pre_layers"] == 2 and F % 4 == 0 and F <= 128 and
+                                              all(w.is_contiguous() for w, _ in (lay["pre"][t][0] for t in range(T)))) else None
+        if tiles is not None:
+            # message assembly -> pre-layer 1 -> aggregate in ONE launch; nothing is kept for a backward here, so neither h1
+            # nor the messages are written at all (gnx_pna_edge_fwd with NULL h1 / m)
+            _, _, A = ops.pna_edge_fwd(P, Q, lay["Te"], pack, T, F, [lay["pre"][t][0][0] for t in range(T)],
+                                       [lay["pre"][t][0][1] for t in range(T)], dc.D - 1, keep=False)
+        else:
+            h = ops.edge_combine_fwd(P, Q, lay["Te"], pack, relu=lay["pre_layers"] > 1)
+            for i in range(lay["pre_layers"] - 1):
+                hn = torch.empty(pack.E, H, device=dev)
+                for t in range(T):
+                    w, b = lay["pre"][t][i]
+                    ops.gemm([(h[:, t * F:(t + 1) * F], None, w)], hn[:, t * F:(t + 1) * F], bias=b,
+                             relu=i < lay["pre_layers"] - 2)
+                h = hn
+            A = ops.pna_aggregate_fwd(h, pack, T, F)
         z = torch.empty(N, H, device=dev)
         relu0 = lay["post_layers"] > 1
         if dc is not None:

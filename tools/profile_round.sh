@@ -2,7 +2,7 @@
 # Collects the round's judged evidence on a GPU box into gpurun_out/<tag>/ (scratch); tools/collect_profiles.py copies
 # the summaries into profiles/.  usage: bash tools/profile_round.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT $OUT/stats $OUT/stats_ns $OUT/pmc/fetch $OUT/pmc/write $OUT/pmc/mfma $OUT/pmc/gui $OUT/stats_cfg3 $OUT/stats_cfg5
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
