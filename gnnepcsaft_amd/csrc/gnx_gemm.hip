@@ -116,6 +116,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, const int (&row
 // purpose: selecting between a kernel-argument pointer and a __constant__ address yields a GENERIC pointer, i.e. a
 // flat_load, and one outstanding flat load turns every counted s_waitcnt vmcnt(N) of the loop into vmcnt(0).
 __device__ float c_one = 1.0f;
+__device__ float c_zero = 0.0f;
+__device__ __attribute__((aligned(16))) float c_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 
 // VEC = every operand is 16-B aligned with leading dimensions / k / class strides multiples of 4 (always true for the
 // model's shapes): loads are unconditional float4 from clamped addresses + a select, so all 8 loads of a K-tile are in
@@ -1387,6 +1389,268 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Activation-stationary split product for SHORT K, WIDE N (one segment, 96 < K <= 128, N a multiple of 128 and >= 256:
+// dA = g . W_eff(d)^T of post-layer 0, K = 128 -> N = 512, per degree class).  k_gemm3 gives every (row tile, column
+// tile) pair its own workgroup, so the same 128 x 128 activation tile is loaded and split N / 128 times; with 4 K-tiles
+// per tile the split costs as much as the MFMAs.  Here a workgroup owns a 64-row tile: loads + splits it ONCE into LDS
+// (three bf16 images, 64 rows x 272 B, 51 KB: three workgroups per CU), then walks the column tiles; wave w multiplies
+// all 64 rows by the columns 32 w .. of the column tile, its B fragments coming straight from the fragment-major weight
+// image in L2 (k_split_weights, frag = 1) through a two-K-tile register ring that is refilled right after each slab's
+// MFMAs and runs on across column-tile boundaries (every load unconditional: past the end the last K-tile is re-read).
+// No predicates anywhere in the column loop, so every s_waitcnt of the ring is exact (vmcnt counts loads AND stores in
+// order; behind a data-dependent number of stores hipcc waits for all of them):
+//   * a partial tile repeats its last valid row (same inputs -> same outputs -> the same value stored to the same
+//     address more than once);
+//   * N % 128 == 0 and all element offsets below 2^30 are launch conditions (else k_gemm3 runs), so a store is a
+//     uniform base + a 32-bit lane offset read from LDS (row * ldc, computed once per tile).
+// Same MFMAs, same operands, same order per accumulator as k_gemm3: bit-identical results.
+// A grouped call's 128-row class tiles (gnx_class_tiles) are taken as two 64-row halves.
+// ---------------------------------------------------------------------------------------------------------------
+#define AS_BM 64
+#define AS_LDA 272                  // bytes per image row: 128 bf16 + 16 (row stride = 17 x 16 B: conflict-free ds_read_b128)
+#define AS_PIECE (AS_BM * AS_LDA)
+#define AS_LDS (3 * AS_PIECE + 2 * AS_BM * 4)
+
+#ifdef AS_STAMP  // diagnostic build only (tools/ubench/gemm_as3_stamp.hip): per-workgroup phase cycle sums
+__device__ unsigned long long* as_stamp_buf = nullptr;
+#define AS_AT(i)                                     \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    const unsigned long long tn_ = clock64();        \
+    tacc[i] += tn_ - tprev;                          \
+    tprev = tn_;                                     \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#else
+#define AS_AT(i)
+#endif
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 3) k_gemm_as3(gemm_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_as[];
+#ifdef AS_STAMP
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tstart = clock64();
+  unsigned long long tprev = tstart;
+#endif
+  unsigned char* const A3 = lds_as;
+  unsigned* const roff = reinterpret_cast<unsigned*>(lds_as + 3 * AS_PIECE);              // row * ldc
+  unsigned* const moff = reinterpret_cast<unsigned*>(lds_as + 3 * AS_PIECE + AS_BM * 4);  // row * ldmask
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int NT = g.Npad / BN;
+  const bool grouped = g.tile_info != nullptr;
+
+  int p0, pr, cls = 0;
+  if (grouped) {
+    const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
+    if (t >= g.ntiles[0]) return;
+    p0 = g.tile_info[3 * t] + AS_BM * half;
+    pr = g.tile_info[3 * t + 1] - AS_BM * half;
+    cls = g.tile_info[3 * t + 2];
+    if (pr <= 0) return;
+    pr = pr < AS_BM ? pr : AS_BM;
+  } else {
+    const int64_t m0 = (int64_t)blockIdx.x * AS_BM;
+    p0 = (int)m0;
+    pr = (int)min((int64_t)AS_BM, g.M - m0);
+  }
+
+  // ---- A tile: 32 lanes cover one 512-byte row, 8 rows per pass, 8 passes; B ring: K-tile 0 of column tile 0
+  const seg_dev& s = g.seg[0];
+  const int lr = tid >> 5, k4 = (tid & 31) * 4;
+  const bool k_ok = k4 < s.k;
+  int grow[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = lr + 8 * q;
+    const int idx = p0 + (r < pr ? r : pr - 1);
+    grow[q] = grouped ? g.row_index[idx] : idx;
+  }
+  int my_row = 0;
+  if (tid < AS_BM) {
+    const int idx = p0 + (tid < pr ? tid : pr - 1);
+    my_row = grouped ? g.row_index[idx] : idx;
+  }
+  f32x4 ra[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ra[q] = *reinterpret_cast<const f32x4*>(s.a + (int64_t)grow[q] * s.lda + (k_ok ? k4 : 0));
+
+  const int total_kt = NT * 4;
+  const __bf16* const bbase = g.bsplit + ((int64_t)cls * NT * 4 * 3) * (BN * BK) + (wave * 64 + lane) * 8;
+  bf16x8 bq[2][2][3];  // [K-tile parity][slab][piece]
+  auto load_b = [&](int slot, int sl, int j) {
+    const __bf16* p = bbase + (int64_t)(j < total_kt ? j : total_kt - 1) * (3 * BN * BK);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bq[slot][sl][pc] = *reinterpret_cast<const bf16x8*>(p + ((sl * 3 + pc) * 4 * 64) * 8);
+  };
+  load_b(0, 0, 0);
+  load_b(0, 1, 0);
+  AS_AT(0);  // tile info, row ids, issue of the A loads
+
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  if (tid < AS_BM) {
+    roff[tid] = (unsigned)my_row * (unsigned)g.ldc;
+    moff[tid] = (unsigned)my_row * (unsigned)g.ldmask;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    float xa[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xa[j] = k_ok ? ra[q][j] : 0.f;
+      xa[4 + j] = k_ok ? ra[q + 1][j] : 0.f;
+    }
+    bf16x8 pc[3];
+    split3(xa, pc[0], pc[1], pc[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
+      unsigned char* qa = A3 + p * AS_PIECE + (lr + 8 * q) * AS_LDA + k4 * 2;
+      *reinterpret_cast<f32x2*>(qa) = f32x2{w.x, w.y};
+      *reinterpret_cast<f32x2*>(qa + 8 * AS_LDA) = f32x2{w.z, w.w};
+    }
+  }
+  load_b(1, 0, 1);  // (after the split: held across it, the second K-tile's 24 registers spill)
+  load_b(1, 1, 1);
+  AS_AT(1);  // wait for A, split, LDS stores
+  __syncthreads();
+  AS_AT(2);
+
+  // A fragments come from LDS for every slab (one slab ahead of its MFMAs).  The offset is made opaque per column tile:
+  // the tile is loop-invariant, and hoisting its 48 fragments (192 VGPRs) out of the column loop spills.  (The OFFSET,
+  // not the pointer: an opaque pointer loses its LDS address space and turns the reads into flat loads.)
+  int afrag = li * AS_LDA + 16 * lh;
+  bf16x8 af[2][2][3];  // [slab parity][mi][piece]
+  auto read_a = [&](int slot, int off, int ks) {  // ks = 16-deep slab 0..7 of the K = 128 tile
+    const unsigned char* base = A3 + off;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        af[slot][mi][p] = *reinterpret_cast<const bf16x8*>(base + p * AS_PIECE + mi * 32 * AS_LDA + ks * 32);
+  };
+  read_a(0, afrag, 0);
+
+  // Epilogue geometry.  The MFMA result has lane = column, 4 consecutive ROWS per register group; a 4 x 4 transpose
+  // inside every quad of lanes (two DPP exchange stages) turns that into lane = (row 8g + 4 lh + j, columns 4c .. 4c+3)
+  // with j = li & 3, c = li >> 2: one 16-byte store per group, 8 lanes per 128-byte line, 8 full lines per wave
+  // instruction (the 4-byte stores of the untransposed layout reached 2.2 TB/s: the epilogue took as long as the MFMAs).
+  const int qj = li & 3;
+  const unsigned lc = (unsigned)(wave * 32 + (li >> 2) * 4);
+  unsigned ro[2][4], mo[2][4];  // row * ldc (row * ldmask) of this lane's 8 stores per column tile
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      ro[mi][gq] = roff[mi * 32 + 8 * gq + 4 * lh + qj] + lc;
+      mo[mi][gq] = moff[mi * 32 + 8 * gq + 4 * lh + qj] + lc;
+    }
+  // bias of the NEXT column tile is fetched a tile ahead (unconditional, from a zero vector when there is none)
+  const float* const bias_p = g.bias != nullptr ? g.bias : c_zero4;
+  const int bias_on = g.bias != nullptr ? 1 : 0;
+  auto bias_at = [&](int nt_) { return *reinterpret_cast<const f32x4*>(bias_p + (bias_on ? nt_ * BN + (int)lc : 0)); };
+  f32x4 bv = bias_at(0);
+  const float floor_v = g.relu ? 0.f : -__builtin_inff();
+  asm volatile("" ::"v"(bv));  // waited for HERE: pending at the loop entry it would cost a vmcnt(0) in every iteration
+  // exchange within lane pairs (xor 1) / across pairs (xor 2) of a quad: x and y swap their off-diagonal elements
+  auto quad_swap = [&](float& x, float& y, auto CTRL, bool hi) {
+    const float send = hi ? x : y;
+    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), decltype(CTRL)::value, 0xf, 0xf, true));
+    x = hi ? got : x;
+    y = hi ? y : got;
+  };
+  using XOR1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]
+  using XOR2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]
+
+  for (int nt = 0; nt < NT; ++nt) {
+    asm volatile("" : "+v"(afrag));
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    const f32x4 bv_next = bias_at(nt + 1 < NT ? nt + 1 : nt);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kt = ks >> 1, sl = ks & 1;
+      read_a((ks + 1) & 1, afrag, (ks + 1) & 7);
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8(&b)[3] = bq[kt & 1][sl];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const bf16x8(&a)[3] = af[ks & 1][mi];
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[mi], 0, 0, 0);
+      }
+      load_b(kt & 1, sl, nt * 4 + kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::"v"(bv_next));  // touched here, where the number of younger loads is static
+    AS_AT(3);  // fragment reads + MFMAs of a column tile
+    float* const cbase = g.C + nt * BN;
+    const float* const mbase = (EPI == EPI_MASK ? g.mask : g.C) + nt * BN;
+    // every load of the accumulate / mask operand precedes every store: a repeated row (partial tile) must read the
+    // ORIGINAL C in all its copies (same wave, same address, program order), or it would be accumulated more than once
+    f32x4 extra[2][4];
+    if constexpr (EPI != EPI_PLAIN) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          extra[mi][gq] = *reinterpret_cast<const f32x4*>(mbase + (EPI == EPI_MASK ? mo[mi][gq] : ro[mi][gq]));
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float c0 = acc[mi][4 * gq], c1 = acc[mi][4 * gq + 1], c2 = acc[mi][4 * gq + 2], c3 = acc[mi][4 * gq + 3];
+        quad_swap(c0, c1, XOR1{}, (qj & 1) != 0);
+        quad_swap(c2, c3, XOR1{}, (qj & 1) != 0);
+        quad_swap(c0, c2, XOR2{}, (qj & 2) != 0);
+        quad_swap(c1, c3, XOR2{}, (qj & 2) != 0);
+        f32x4 v = {c0 + bv.x, c1 + bv.y, c2 + bv.z, c3 + bv.w};
+        if constexpr (EPI == EPI_ACCUM) v += extra[mi][gq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
+        if constexpr (EPI == EPI_MASK)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (extra[mi][gq][e] > 0.f) ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(cbase + ro[mi][gq]) = v;
+      }
+    bv = bv_next;
+    AS_AT(4);  // epilogue
+  }
+#ifdef AS_STAMP
+  if (tid == 0 && as_stamp_buf != nullptr) {
+    for (int i = 0; i < 5; ++i) as_stamp_buf[(size_t)blockIdx.x * 8 + i] = tacc[i];
+    as_stamp_buf[(size_t)blockIdx.x * 8 + 5] = tstart;
+    as_stamp_buf[(size_t)blockIdx.x * 8 + 6] = clock64();
+  }
+#endif
+}
+
+template <int EPI>
+static hipError_t as3_launch_one(gnx_handle* h, const gemm_args& g, unsigned grid) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_as3<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AS_LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gemm_as3<EPI>), dim3(grid), dim3(256), AS_LDS, h->stream, g);
+  return hipSuccess;
+}
+
 template <bool BT, int EPI>
 static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
   static bool attr_set = false;
@@ -1712,6 +1976,7 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   }
   const dim3 grid3(g3);
   bool pipe = h->opt[GNX_OPT_GEMM_PIPE] != 0;  // decided below: needs >= G3P_MIN_KTILES K-tiles per output tile
+  bool as3 = false;                            // decided below: one segment, 4 K-tiles, >= 2 column tiles
   bool vec = h->opt[GNX_OPT_GEMM_VEC] != 0;
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
@@ -1745,7 +2010,10 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     sa.Kpad = kp;
     sa.D = num_classes > 0 ? num_classes : 1;
     pipe = pipe && kp / BK >= G3P_MIN_KTILES;
-    sa.frag = pipe ? 1 : 0;
+    as3 = h->opt[GNX_OPT_GEMM_AS] != 0 && nseg == 1 && kp == 4 * BK && N >= 2 * BN && N % BN == 0 &&
+          (double)M * (double)(ldc > ldmask ? ldc : ldmask) + (double)N < 1073741824.0 && aligned16(C) && ldc % 4 == 0 &&
+          (mask == nullptr || (aligned16(mask) && ldmask % 4 == 0)) && (bias == nullptr || aligned16(bias));
+    sa.frag = (pipe || as3) ? 1 : 0;
     sa.out = reinterpret_cast<__bf16*>(ws);
     const int64_t items = (int64_t)sa.D * sa.Npad * (sa.Kpad / 8);
     if (bt)
@@ -1761,7 +2029,10 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
     if (split) {                                                                          \
-      if (pipe)                                                                           \
+      if (as3) {                                                                          \
+        const unsigned ga = tile_info ? (unsigned)(2 * max_tiles) : (unsigned)gnx_cdiv(M, AS_BM); \
+        GNX_HIP(as3_launch_one<EPI>(h, g, ga));                                           \
+      } else if (pipe)                                                                    \
         hipLaunchKernelGGL((k_gemm3p<EPI>), grid3, dim3(256), G3P_LDS, h->stream, g);     \
       else                                                                                \
         hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);            \

@@ -68,7 +68,8 @@ enum {
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
   GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd / _bwd take the fused edge kernels (gnx_pna_edge_fwd / gnx_pna_edge_bwd) when eligible (bit-identical messages, h1, aggregate, gh1, dP); 2: forward only; 0: three launches each */
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
-  GNX_OPT_COUNT = 12
+  GNX_OPT_GEMM_AS = 12,          /* 1: split products with one segment, 96 < K <= 128 and N >= 256 take the activation-stationary kernel (the row tile is split once for all column tiles; bit-identical results) */
+  GNX_OPT_COUNT = 13
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);

@@ -194,6 +194,77 @@ def test_pipelined_and_two_barrier_tiled_kernels_are_bit_identical(gpu_device):
     assert not torch.isnan(p).any()
 
 
+def test_activation_stationary_and_two_barrier_kernels_are_bit_identical(gpu_device):
+    """k_gemm_as3 (one segment, 96 < K <= 128, N a multiple of 128 >= 256: the row tile is split once for all column
+    tiles; a partial tile repeats its last row instead of predicating) against k_gemm3 (GNX_OPT_GEMM_AS = 0): same MFMAs
+    per accumulator -> bit-identical, for every epilogue, a ragged last tile, K below 128, a strided output view that
+    must stay untouched outside, and the degree-class grouped dA product."""
+    from gnnepcsaft_amd import ops
+    dev = torch.device("cuda:0")
+
+    def both(fn):
+        outs = []
+        for on in (1, 0):
+            ops.set_option(dev, _lib.OPT_GEMM_AS, on)
+            try:
+                outs.append(fn())
+            finally:
+                ops.set_option(dev, _lib.OPT_GEMM_AS, 1)
+        return outs
+
+    torch.manual_seed(77)
+    for M, N, K in [(8200, 512, 128), (4099, 256, 100), (70001, 384, 128)]:
+        a, w = torch.randn(M, K), torch.randn(K, N) / 4
+        mask, c0, b = torch.randn(M, N), torch.randn(M, N), torch.randn(N)
+        ad, wd, md, bd = a.to(gpu_device), w.to(gpu_device), mask.to(gpu_device), b.to(gpu_device)
+        prod = a.double() @ w.double()
+
+        def plain():
+            out = torch.full((M, N + 24), float("nan"), device=gpu_device)
+            ops.gemm([(ad, None, wd)], out[:, 8:8 + N], b_trans=False)
+            return out
+        p, q = both(plain)
+        assert torch.equal(p[:, 8:8 + N], q[:, 8:8 + N]) and rel_err(p[:, 8:8 + N], prod) <= TOL
+        assert torch.isnan(p[:, :8]).all() and torch.isnan(p[:, 8 + N:]).all()
+
+        def masked():
+            out = torch.full((M, N), float("nan"), device=gpu_device)
+            ops.gemm([(ad, None, wd)], out, b_trans=False, mask=md)
+            return out
+        p, q = both(masked)
+        assert torch.equal(p, q) and rel_err(p, prod * (mask > 0)) <= TOL
+
+        def accum():
+            out = c0.clone().to(gpu_device)
+            ops.gemm([(ad, None, wd)], out, b_trans=False, accumulate=True)
+            return out
+        p, q = both(accum)
+        assert torch.equal(p, q) and rel_err(p, c0.double() + prod) <= TOL
+
+        def bias_relu():
+            out = torch.full((M, N), float("nan"), device=gpu_device)
+            ops.gemm([(ad, None, wd.T.contiguous())], out, bias=bd, relu=True)
+            return out
+        p, q = both(bias_relu)
+        assert torch.equal(p, q) and rel_err(p, (prod + b.double()).relu()) <= TOL
+    # grouped dA: rows gathered per in-degree class, per-class weights, K = 128 -> N = 512
+    rng = np.random.default_rng(8)
+    Nn, E, F = 50011, 120000, 128
+    g = _pack(_graph(rng, Nn, E), None, None, Nn, None, gpu_device)
+    dc = g.degree_classes()
+    assert dc is not None
+    Wp = torch.randn(F, 13 * F, device=gpu_device) / 8
+    weff = ops.pna_weff(Wp, F, dc.D, 1.2)
+    gr = torch.randn(Nn, F, device=gpu_device)
+
+    def grouped():
+        dA = torch.full((Nn, 4 * F), float("nan"), device=gpu_device)
+        ops.gemm_grouped([(gr, None, weff[0], 4 * F * F)], dA, dc, b_trans=False)
+        return dA
+    p, q = both(grouped)
+    assert torch.equal(p, q) and not torch.isnan(p).any()
+
+
 def test_split_and_exact_kernels_agree(gpu_device):
     """Same call through the split-operand kernel and the exact-fp32 MFMA kernel: both within 1e-5 of fp64 and within
     2e-6 (norm-wise) of each other."""
