@@ -559,7 +559,15 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 // ---------------------------------------------------------------------------------------------------------------
 #include "gnx_split.hpp"
 
-template <bool B_TRANS, int EPI>
+//
+// FAST (N == 128, 16-byte aligned C / mask, no accumulate): a predicate-free tile loop.  The result tile is transposed
+// 4 x 4 inside every quad of lanes (two DPP exchange stages: lane = column, four rows per register group -> lane = row,
+// four columns) and leaves as four 16-byte stores per lane, 8 full 128-byte lines per wave instruction; a partial last
+// tile repeats row M - 1 (same inputs -> same value to the same address) and the next tile's loads are always issued
+// (past the end: the current tile again), so no branch sits between the loads of tile t + G and their first use and the
+// wait in front of the split is an exact vmcnt(stores issued since) -- with the predicated 4-byte epilogue hipcc could
+// not count the stores and drained ALL of them (write acknowledgements, ~1 us) before every split.
+template <bool B_TRANS, int EPI, bool FAST>
 __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
   const int tid = threadIdx.x;
@@ -584,7 +592,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
     for (int i = 0; i < 4; ++i) {
       const int64_t gm = m0 + ar + 16 * i;
       ra[i] = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
-      okmask |= (ak_ok && gm < g.M) ? (1 << i) : 0;
+      okmask |= (ak_ok && (FAST || gm < g.M)) ? (1 << i) : 0;  // FAST: rows past the end repeat row M - 1
     }
   };
   typedef __attribute__((ext_vector_type(2))) float f32x2;  // 8-byte LDS word (four bf16)
@@ -660,10 +668,31 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   store_a(lds3);
   __syncthreads();
 
+  // FAST epilogue geometry (see above)
+  const int qj = li & 3, colq = wc + (li >> 2) * 4;
+  f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+  if (FAST && g.bias != nullptr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv4[e] = g.bias[colq + e];
+  const float floor_v = g.relu ? 0.f : -__builtin_inff();
+  auto quad_swap = [&](float& x, float& y, auto CTRL, bool hi) {
+    const float send = hi ? x : y;
+    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), decltype(CTRL)::value, 0xf, 0xf, true));
+    x = hi ? got : x;
+    y = hi ? y : got;
+  };
+  using XOR1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]
+  using XOR2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]
+
   while (tile < g.ntiles) {
     const int next = tile + gridDim.x;
     const bool has_next = next < g.ntiles;
-    if (has_next) load_a(next);
+    if (FAST) {
+      load_a(has_next ? next : tile);
+      __builtin_amdgcn_sched_barrier(0);  // (hipcc sinks these loads below the MFMA slabs otherwise)
+    } else if (has_next) {
+      load_a(next);
+    }
     const int64_t m0 = (int64_t)tile * W3_BM;
 
     f32x16 acc, corr;
@@ -690,7 +719,33 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += corr[r];
 
-    if (m0 + W3_BM <= g.M) {
+    if constexpr (FAST) {
+      const int64_t rbase = m0 + wr + 4 * lh + qj, rlast = g.M - 1;
+      f32x4 ex[4];
+      if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int64_t gr = rbase + 8 * gq < rlast ? rbase + 8 * gq : rlast;
+          ex[gq] = *reinterpret_cast<const f32x4*>(g.mask + gr * g.ldmask + colq);
+        }
+      }
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float c0 = acc[4 * gq], c1 = acc[4 * gq + 1], c2 = acc[4 * gq + 2], c3 = acc[4 * gq + 3];
+        quad_swap(c0, c1, XOR1{}, (qj & 1) != 0);
+        quad_swap(c2, c3, XOR1{}, (qj & 1) != 0);
+        quad_swap(c0, c2, XOR2{}, (qj & 2) != 0);
+        quad_swap(c1, c3, XOR2{}, (qj & 2) != 0);
+        f32x4 v = {c0 + bv4.x, c1 + bv4.y, c2 + bv4.z, c3 + bv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
+        if constexpr (EPI == EPI_MASK)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (ex[gq][e] > 0.f) ? v[e] : 0.f;
+        const int64_t gr = rbase + 8 * gq < rlast ? rbase + 8 * gq : rlast;
+        *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + colq) = v;
+      }
+    } else if (m0 + W3_BM <= g.M) {
       epilogue_tile_full<EPI>(acc, m0 + wr + 4 * lh, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
     } else {
       int rows[16];
@@ -1651,17 +1706,26 @@ static hipError_t as3_launch_one(gnx_handle* h, const gemm_args& g, unsigned gri
   return hipSuccess;
 }
 
-template <bool BT, int EPI>
-static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
+template <bool BT, int EPI, bool FAST>
+static hipError_t ws3_launch_fast(gnx_handle* h, const ws_args& g, int grid) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws3<BT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws3<BT, EPI, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm_ws3<BT, EPI>), dim3(grid), dim3(512), 2 * W3_BUF, h->stream, g);
+  hipLaunchKernelGGL((k_gemm_ws3<BT, EPI, FAST>), dim3(grid), dim3(512), 2 * W3_BUF, h->stream, g);
   return hipGetLastError();
+}
+
+template <bool BT, int EPI>
+static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
+  // the predicate-free kernel: all 128 columns, 16-byte stores (and mask loads), no read-modify-write of C
+  const bool fast = h->opt[GNX_OPT_GEMM_WS_FAST] != 0 && EPI != EPI_ACCUM && g.N == 128 && aligned16(g.C) && g.ldc % 4 == 0 &&
+                    (g.mask == nullptr || (aligned16(g.mask) && g.ldmask % 4 == 0));
+  if (EPI != EPI_ACCUM && fast) return ws3_launch_fast<BT, EPI, EPI != EPI_ACCUM>(h, g, grid);
+  return ws3_launch_fast<BT, EPI, false>(h, g, grid);
 }
 
 static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, int32_t N, const float* bias,

@@ -69,7 +69,8 @@ enum {
   GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd / _bwd take the fused edge kernels (gnx_pna_edge_fwd / gnx_pna_edge_bwd) when eligible (bit-identical messages, h1, aggregate, gh1, dP); 2: forward only; 0: three launches each */
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
   GNX_OPT_GEMM_AS = 12,          /* 1: split products with one segment, 96 < K <= 128 and N >= 256 take the activation-stationary kernel (the row tile is split once for all column tiles; bit-identical results) */
-  GNX_OPT_COUNT = 13
+  GNX_OPT_GEMM_WS_FAST = 13,     /* 1: the weights-stationary split kernel takes its predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate (bit-identical results) */
+  GNX_OPT_COUNT = 14
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);

@@ -36,6 +36,55 @@ def test_gemm_ws_variants(gpu_device, M, N, K, b_trans):
     assert rel_err(out, c0.double() + prod + b.double()) <= TOL
 
 
+@pytest.mark.parametrize("M,K", [(8192, 128), (20001, 128), (81920 + 37, 128), (10000, 100)])
+@pytest.mark.parametrize("b_trans", [True, False])
+def test_predicate_free_and_predicated_ws3_are_bit_identical(gpu_device, M, K, b_trans):
+    """k_gemm_ws3<.., FAST> (N = 128: quad-transposed 16-byte stores, a partial last tile repeats row M - 1, exact
+    waits) against the predicated form (GNX_OPT_GEMM_WS_FAST = 0): same MFMAs -> bit-identical outputs for the plain /
+    bias + ReLU / mask epilogues, a ragged last tile, K below 128, and a strided output view that stays untouched outside."""
+    from gnnepcsaft_amd import ops
+    dev = torch.device("cuda:0")
+    N = 128
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K, device=gpu_device)
+    w = torch.randn(N, K, device=gpu_device) if b_trans else torch.randn(K, N, device=gpu_device)
+    b, mask = torch.randn(N, device=gpu_device), torch.randn(M, N, device=gpu_device)
+
+    def both(fn):
+        outs = []
+        for on in (1, 0):
+            ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, on)
+            try:
+                outs.append(fn())
+            finally:
+                ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1)
+        return outs
+
+    def bias_relu():
+        out = torch.full((M + 3, N + 8), float("nan"), device=gpu_device)
+        ops.gemm([(a, None, w)], out[:M, 4:4 + N], bias=b, relu=True, b_trans=b_trans)
+        return out
+    p, q = both(bias_relu)
+    assert torch.equal(p[:M, 4:4 + N], q[:M, 4:4 + N]) and not torch.isnan(p[:M, 4:4 + N]).any()
+    assert torch.isnan(p[M:]).all() and torch.isnan(p[:, :4]).all() and torch.isnan(p[:, 4 + N:]).all()
+
+    def plain():
+        out = torch.full((M, N), float("nan"), device=gpu_device)
+        ops.gemm([(a, None, w)], out, b_trans=b_trans)
+        return out
+    p, q = both(plain)
+    assert torch.equal(p, q)
+
+    def masked():
+        out = torch.full((M, N), float("nan"), device=gpu_device)
+        ops.gemm([(a, None, w)], out, b_trans=b_trans, mask=mask)
+        return out
+    p, q = both(masked)
+    assert torch.equal(p, q)
+    prod = a.double() @ (w.double().T if b_trans else w.double())
+    assert rel_err(p, prod * (mask > 0)) <= TOL
+
+
 def test_gemm_ws_strided_views_and_guard_rows(gpu_device):
     """Tower-style column slices (lda = ldc = H > K) and no write outside the output view."""
     from gnnepcsaft_amd import ops
