@@ -14,7 +14,7 @@ ABI_VERSION = 3
 GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
 # gnx_set_option ids (include/gnx.h)
 OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
-    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS, OPT_GEMM_AS, OPT_GEMM_WS_FAST = range(14)
+    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS, OPT_GEMM_AS, OPT_GEMM_WS_FAST, OPT_GEMM_TILE_ROWS = range(15)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
@@ -59,7 +59,7 @@ class PnaFwdArgs(C.Structure):
                 ("max_tiles", _i64), ("x", _vp), ("Te", _vp), ("weff", _vp * PNA_MAX_TOWERS), ("Wm", _vp), ("bm", _vp),
                 ("params", C.POINTER(_vp)), ("P", _vp), ("Q", _vp), ("A", _vp), ("hs", _vp * PNA_MAX_LAYERS),
                 ("zs", _vp * PNA_MAX_LAYERS), ("ws", _vp), ("ws_bytes", _sz), ("out", _vp), ("etile_info", _vp),
-                ("etile_w", _i32), ("_pad", _i32)]
+                ("etile_w", _i32), ("tile_rows", _i32)]
 
 
 class PnaBwdArgs(C.Structure):
@@ -128,6 +128,9 @@ SIGNATURES = {
     "gnx_class_tiles": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "gnx_gemm_grouped": (_i32, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i32, _i64, _i32, _vp, _vp, _i64, _vp,
                                 _i64, _i32, _vp, _vp, _vp, _i64, _vp, _sz]),
+    "gnx_gemm_tile_rows": (_i32, [_vp, _i64, _i32]),
+    "gnx_gemm_grouped_rows": (_i32, [_vp, _i32, C.POINTER(GemmSeg), C.POINTER(_i64), _i32, _i64, _i32, _vp, _vp, _i64, _vp,
+                                     _i64, _i32, _vp, _vp, _vp, _i64, _vp, _sz, _i32]),
     "gnx_gemm_wgrad_grouped": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp,
                                       _i64]),
     "gnx_pna_weff": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),

@@ -1148,13 +1148,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
 // ---------------------------------------------------------------------------------------------------------------
 #define G3P_STAGES 2
 #define G3P_MIN_KTILES 12  // shorter K: the two-barrier kernel is as fast (measured at 4 and 8 K-tiles) and has the shorter prologue
-#define G3P_LDS (G3P_STAGES * G3_OP + 2 * BM * 4)
+#define G3P_LDS(MI) (G3P_STAGES * 3 * 32 * (MI) * G3_LDB + 2 * 32 * (MI) * 4)
 
-template <int EPI>
+// MI = 32-row blocks per tile (4: 128-row tiles; 3: 96-row tiles, taken when 128-row tiles leave the last round of the
+// persistent workgroups mostly idle: cfg-2's 81 920 rows are 640 tiles for 512 workgroup slots).  Same arithmetic per row.
+// Measured (round 3, same-box A/B of the cfg-2 step, 6.97-7.05 ms): 96-row tiles -0.01...-0.02 ms only -- the CU, not the
+// workgroup slot, is the unit to balance (854 x 0.75 tiles are the same 2.5 tile-equivalents per CU as 640, and a workgroup
+// alone on its CU runs nearly twice as fast); 160-row tiles (MI = 5: exactly two per CU, a fifth less B traffic per row, but
+// 248 VGPRs and 76 KB of LDS) were +0.06 ms and are not instantiated.
+template <int EPI, int MI>
 __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
+  constexpr int TM = 32 * MI;             // rows per tile
+  constexpr int PIECE = TM * G3_LDB;      // one bf16 image of a TM x 32 K-tile
+  constexpr int OP = 3 * PIECE;           // the three images
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_p[];
-  unsigned char* const Abuf = lds_p;                                     // [2][G3_OP]
-  int* const rid = reinterpret_cast<int*>(lds_p + G3P_STAGES * G3_OP);   // [2][BM]
+  unsigned char* const Abuf = lds_p;                                  // [2][OP]
+  int* const rid = reinterpret_cast<int*>(lds_p + G3P_STAGES * OP);   // [2][TM]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1168,7 +1177,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
 
   const int ny = g.ny, G = gridDim.x;
   const bool grouped = g.tile_info != nullptr;
-  const int nrt = grouped ? g.ntiles[0] : (int)((g.M + BM - 1) / BM);
+  const int nrt = grouped ? g.ntiles[0] : (int)((g.M + TM - 1) / TM);
   auto row_tile_of = [&](int v) { return (v / (8 * ny)) * 8 + ((v % (8 * ny)) & 7); };
   auto n0_of = [&](int v) { return ((v % (8 * ny)) >> 3) * BN; };
 
@@ -1184,31 +1193,31 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
   };
   // row ids of a tile: RAW loaded values; the r < rows select is applied where the ids are consumed, a tile later (a
   // select right here would wait for these loads, and with them for every K-tile load in flight, at each tile switch)
-  auto fetch_rows = [&](int v, int p0, int pr, int c, int (&gr)[4], int& rt_id, int& cl) {
-    const int t = tid < BM ? tid : 0;
+  auto fetch_rows = [&](int v, int p0, int pr, int c, int (&gr)[MI], int& rt_id, int& cl) {
+    const int t = tid < TM ? tid : 0;
     if (grouped) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < MI; ++q) {
         const int r = lrow + 32 * q;
         gr[q] = g.row_index[p0 + (r < pr ? r : 0)];
       }
       rt_id = g.row_index[p0 + (t < pr ? t : 0)];
       cl = c;
     } else {
-      const int64_t m0 = (int64_t)row_tile_of(v) * BM;
+      const int64_t m0 = (int64_t)row_tile_of(v) * TM;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gr[q] = (int)(m0 + lrow + 32 * q);
+      for (int q = 0; q < MI; ++q) gr[q] = (int)(m0 + lrow + 32 * q);
       rt_id = (int)(m0 + t);
       cl = 0;
     }
   };
   auto rows_in_tile = [&](int v, int pr) {
-    return grouped ? pr : (int)min((int64_t)BM, g.M - (int64_t)row_tile_of(v) * BM);
+    return grouped ? pr : (int)min((int64_t)TM, g.M - (int64_t)row_tile_of(v) * TM);
   };
 
   // A cursor's tile (cgrow), the tile after it (grow_n ..: row ids fetched one tile ahead, its tile_info two ahead), and
   // what the multiply / the B cursor take over when they reach the tile the A cursor has entered (ridt_p, n0_p, cls_p)
-  int cgrow[4], grow_n[4] = {0, 0, 0, 0}, ridt_n = 0, pr_n = 0, cls_n = 0, n0_n = 0, ti2_p0 = 0, ti2_pr = 0, ti2_cls = 0;
+  int cgrow[MI], grow_n[MI] = {}, ridt_n = 0, pr_n = 0, cls_n = 0, n0_n = 0, ti2_p0 = 0, ti2_pr = 0, ti2_cls = 0;
   int n0_c, ridt_p = -1, n0_p = 0, cls_p = 0;
   bool valid_n, pend = false, cursor_valid = true;
   int tpar = 0, cls0 = 0;
@@ -1219,8 +1228,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
     {
       const int nr = rows_in_tile(v_l, pr);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) cgrow[q] = (lrow + 32 * q < nr) ? cgrow[q] : -1;
-      if (tid < BM) rid[tid] = tid < nr ? rt_id : -1;
+      for (int q = 0; q < MI; ++q) cgrow[q] = (lrow + 32 * q < nr) ? cgrow[q] : -1;
+      if (tid < TM) rid[tid] = tid < nr ? rt_id : -1;
     }
     n0_c = n0_of(v_l);
     valid_n = row_tile_of(v_l + G) < nrt;
@@ -1234,24 +1243,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
     cls0 = cl;
   }
 
-  f32x16 acc[4];
+  f32x16 acc[MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  f32x4 ra[2][4];          // A K-tiles in flight (fp32), two register stages
+  f32x4 ra[2][MI];          // A K-tiles in flight (fp32), two register stages
   int kvalid[2] = {0, 0};
   bf16x8 bfr[2][3];        // B fragments [slab][piece]: a slab is refilled (next K-tile) right after its MFMAs
 
   // ---- A cursor
-  const float* rowp[4];
+  const float* rowp[MI];
   int rowv = 0, segK = 0, s1 = 0, k1 = 0;
   auto enter_segment = [&](int s_i) {
     const seg_dev& s = g.seg[s_i];
     rowv = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < MI; ++q) {
       rowp[q] = s.a + (int64_t)(cgrow[q] >= 0 ? cgrow[q] : 0) * s.lda;
       rowv |= cgrow[q] >= 0 ? (1 << q) : 0;
     }
@@ -1263,7 +1272,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
     const bool k_ok = k < segK;
     const int kc = k_ok ? k : 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ra[P][q] = *reinterpret_cast<const f32x4*>(rowp[q] + kc);
+    for (int q = 0; q < MI; ++q) ra[P][q] = *reinterpret_cast<const f32x4*>(rowp[q] + kc);
     kvalid[P] = (k_ok && cursor_valid) ? rowv : 0;
   };
   auto cursor_step = [&]() {
@@ -1279,7 +1288,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
     s1 = 0;
     if (valid_n) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) cgrow[q] = (lrow + 32 * q < pr_n) ? grow_n[q] : -1;
+      for (int q = 0; q < MI; ++q) cgrow[q] = (lrow + 32 * q < pr_n) ? grow_n[q] : -1;
       enter_segment(0);
       ridt_p = tid < pr_n ? ridt_n : -1;
       n0_p = n0_n;
@@ -1327,20 +1336,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
   auto store_a = [&](auto PC, unsigned char* A3) {  // register stage P -> LDS stage at A3
     constexpr int P = decltype(PC)::value;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < (MI + 1) / 2; ++h) {
       float xa[8];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xa[4 * q + j] = ((kvalid[P] >> (2 * h + q)) & 1) ? ra[P][2 * h + q][j] : 0.f;
+        for (int j = 0; j < 4; ++j)
+          xa[4 * q + j] = (2 * h + q < MI && ((kvalid[P] >> (2 * h + q)) & 1)) ? ra[P][2 * h + q < MI ? 2 * h + q : 0][j] : 0.f;
       bf16x8 pc[3];
       split3(xa, pc[0], pc[1], pc[2]);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
-        unsigned char* qa = A3 + p * G3_PIECE + (lrow + 64 * h) * G3_LDB + lk4 * 2;
+        unsigned char* qa = A3 + p * PIECE + (lrow + 64 * h) * G3_LDB + lk4 * 2;
         *reinterpret_cast<f32x2*>(qa) = f32x2{w.x, w.y};
-        *reinterpret_cast<f32x2*>(qa + 32 * G3_LDB) = f32x2{w.z, w.w};
+        if (2 * h + 1 < MI) *reinterpret_cast<f32x2*>(qa + 32 * G3_LDB) = f32x2{w.z, w.w};
       }
     }
   };
@@ -1348,11 +1358,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
   auto read_a1 = [&](const unsigned char* A3, int sl, int mi, bf16x8 (&a)[3]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      a[p] = *reinterpret_cast<const bf16x8*>(A3 + p * G3_PIECE + afrag + mi * 32 * G3_LDB + 32 * sl);
+      a[p] = *reinterpret_cast<const bf16x8*>(A3 + p * PIECE + afrag + mi * 32 * G3_LDB + 32 * sl);
   };
-  auto read_a = [&](const unsigned char* A3, int sl, bf16x8 (&a)[4][3]) {
+  auto read_a = [&](const unsigned char* A3, int sl, bf16x8 (&a)[MI][3]) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) read_a1(A3, sl, mi, a[mi]);
+    for (int mi = 0; mi < MI; ++mi) read_a1(A3, sl, mi, a[mi]);
   };
   auto mfma_group = [&](f32x16& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
@@ -1391,28 +1401,28 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
   int kc = 0;
   bool done = false;
   auto iteration = [&](auto SC, auto PC) {  // S = j & 1: LDS stage of K-tile j; P = 1 - S: register stage of K-tile j + 1
-    const unsigned char* const Ac = Abuf + decltype(SC)::value * G3_OP;
-    unsigned char* const As = Abuf + decltype(PC)::value * G3_OP;
+    const unsigned char* const Ac = Abuf + decltype(SC)::value * OP;
+    unsigned char* const As = Abuf + decltype(PC)::value * OP;
     // multiply K-tile j || split K-tile j + 1 into the other LDS stage || refill each slab's B fragments (K-tile j + 1)
-    bf16x8 af[4][3];
+    bf16x8 af[MI][3];
     read_a(Ac, 0, af);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       mfma_group(acc[mi], af[mi], bfr[0]);
       read_a1(Ac, 1, mi, af[mi]);
     }
     load_b(0);
     store_a(PC, As);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) mfma_group(acc[mi], af[mi], bfr[1]);
+    for (int mi = 0; mi < MI; ++mi) mfma_group(acc[mi], af[mi], bfr[1]);
     load_b(1);
     b_step();
     load_a(PC);  // A K-tile j + 3 (register stage P was stored just above)
     if (++kc == KT) {  // tile finished
-      const int* rt = rid + tpar * BM;
+      const int* rt = rid + tpar * TM;
       const int gc = n0_c + wave * 32 + li;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         int rows[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) rows[r] = rt[mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
@@ -1427,7 +1437,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3p(gemm_args g) {
       // take over the tile the A cursor entered three K-tiles ago (other rid stage: its last readers were the epilogue
       // of the tile before this one)
       tpar ^= 1;
-      if (tid < BM) rid[tpar * BM + tid] = ridt_p;
+      if (tid < TM) rid[tpar * TM + tid] = ridt_p;
       n0_c = n0_p;
       fetch_bias(n0_c);
       pend = false;
@@ -1964,11 +1974,36 @@ static size_t gemm_split_bytes(const gnx_handle* h, int32_t nseg, const gnx_gemm
   return (size_t)(D * 3 * npad * kpad) * sizeof(__bf16);
 }
 
+// Row-tile height of the pipelined tiled product for M rows x N columns: 96 where that shortens the longest workgroup's
+// walk (rounds x tile height; persistent workgroups, two per CU), else 128.  GNX_OPT_GEMM_TILE_ROWS forces 96 / 128.
+static int gemm_pipe_tile_rows(const gnx_handle* h, int64_t M, int32_t N) {
+  const int forced = h->opt[GNX_OPT_GEMM_TILE_ROWS];
+  if (forced == 96 || forced == 128) return forced;
+  const int64_t ny = gnx_cdiv((int64_t)N, BN);
+  const int64_t slots = 2 * (int64_t)(h->num_cus > 0 ? h->num_cus : 256);
+  int best = 128;
+  int64_t best_cost = gnx_cdiv(gnx_cdiv(M, (int64_t)128) * ny, slots) * 128;
+  for (int rows : {96}) {  // strictly shorter longest walk only (ties keep 128, the most measured shape)
+    const int64_t c = gnx_cdiv(gnx_cdiv(M, (int64_t)rows) * ny, slots) * rows;
+    if (c < best_cost) {
+      best_cost = c;
+      best = rows;
+    }
+  }
+  return best;
+}
+
+extern "C" int32_t gnx_gemm_tile_rows(gnx_handle* h, int64_t M, int32_t N) {
+  if (h == nullptr || M <= 0 || N <= 0) return 128;
+  return gemm_pipe_tile_rows(h, M, N);
+}
+
 static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
                            int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask, int64_t ldmask, float* C,
                            int64_t ldc, int32_t flags, const int32_t* row_index, const int32_t* tile_info,
-                           const int32_t* ntiles, int64_t max_tiles, void* ws, size_t ws_bytes) {
+                           const int32_t* ntiles, int64_t max_tiles, void* ws, size_t ws_bytes, int32_t tile_rows = 0) {
   GNX_CHECK_ARG(h && segs && C, "gnx_gemm: NULL argument");
+  GNX_CHECK_ARG(tile_rows == 0 || tile_rows == 96 || tile_rows == 128, "gnx_gemm: tile_rows=%d not in {0, 96, 128}", tile_rows);
   GNX_CHECK_ARG(nseg >= 1 && nseg <= MAX_SEGS, "gnx_gemm: nseg=%d not in [1,%d]", nseg, MAX_SEGS);
   GNX_CHECK_ARG(M >= 0 && N > 0 && ldc >= N, "gnx_gemm: bad shape M=%lld N=%d ldc=%lld", (long long)M, N, (long long)ldc);
   GNX_CHECK_ARG(!((flags & GNX_GEMM_RELU) && (flags & GNX_GEMM_ACCUMULATE)), "gnx_gemm: relu+accumulate rejected");
@@ -2029,18 +2064,19 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   g.ny = (int)grid.y;
-  // k_gemm3: persistent workgroups, two per CU, count a multiple of 8 * ny (the XCD-aware tile walk needs it)
-  unsigned g3 = (unsigned)(gnx_cdiv((int64_t)grid.x, 8) * 8 * grid.y);
-  {
+  // k_gemm3 / k_gemm3p: persistent workgroups, two per CU, count a multiple of 8 * ny (the XCD-aware tile walk needs it)
+  auto persistent_grid = [&](unsigned row_tiles) {
+    unsigned g3 = (unsigned)(gnx_cdiv((int64_t)row_tiles, 8) * 8 * grid.y);
     const unsigned unit = 8u * grid.y;
     unsigned slots = 2u * (unsigned)(h->num_cus > 0 ? h->num_cus : 256);
     slots = slots / unit * unit;
     if (slots < unit) slots = unit;
-    if (g3 > slots) g3 = slots;
-  }
-  const dim3 grid3(g3);
+    return g3 > slots ? slots : g3;
+  };
+  dim3 grid3(persistent_grid(grid.x));
   bool pipe = h->opt[GNX_OPT_GEMM_PIPE] != 0;  // decided below: needs >= G3P_MIN_KTILES K-tiles per output tile
   bool as3 = false;                            // decided below: one segment, 4 K-tiles, >= 2 column tiles
+  bool mi3 = false;                            // pipelined kernel with 96-row tiles
   bool vec = h->opt[GNX_OPT_GEMM_VEC] != 0;
   for (int s = 0; s < nseg; ++s)
     vec = vec && g.seg[s].vec_a && g.seg[s].vec_b && (g.seg[s].k % 4 == 0) && (bt || (N % 4 == 0));
@@ -2074,6 +2110,11 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     sa.Kpad = kp;
     sa.D = num_classes > 0 ? num_classes : 1;
     pipe = pipe && kp / BK >= G3P_MIN_KTILES;
+    if (pipe) {  // tile height of the pipelined kernel: the caller's (grouped: what its tile table was built with) or ours
+      const int rows = tile_info ? (tile_rows ? tile_rows : BM) : (tile_rows ? tile_rows : gemm_pipe_tile_rows(h, M, N));
+      mi3 = rows == 96;
+      if (!tile_info) grid3 = dim3(persistent_grid((unsigned)gnx_cdiv(M, (int64_t)rows)));
+    }
     as3 = h->opt[GNX_OPT_GEMM_AS] != 0 && nseg == 1 && kp == 4 * BK && N >= 2 * BN && N % BN == 0 &&
           (double)M * (double)(ldc > ldmask ? ldc : ldmask) + (double)N < 1073741824.0 && aligned16(C) && ldc % 4 == 0 &&
           (mask == nullptr || (aligned16(mask) && ldmask % 4 == 0)) && (bias == nullptr || aligned16(bias));
@@ -2096,8 +2137,10 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
       if (as3) {                                                                          \
         const unsigned ga = tile_info ? (unsigned)(2 * max_tiles) : (unsigned)gnx_cdiv(M, AS_BM); \
         GNX_HIP(as3_launch_one<EPI>(h, g, ga));                                           \
-      } else if (pipe)                                                                    \
-        hipLaunchKernelGGL((k_gemm3p<EPI>), grid3, dim3(256), G3P_LDS, h->stream, g);     \
+      } else if (pipe && mi3)                                                             \
+        hipLaunchKernelGGL((k_gemm3p<EPI, 3>), grid3, dim3(256), G3P_LDS(3), h->stream, g); \
+      else if (pipe)                                                                      \
+        hipLaunchKernelGGL((k_gemm3p<EPI, 4>), grid3, dim3(256), G3P_LDS(4), h->stream, g); \
       else                                                                                \
         hipLaunchKernelGGL((k_gemm3<EPI>), grid3, dim3(256), 0, h->stream, g);            \
     } else if (vec)                                                                       \
@@ -2147,6 +2190,18 @@ extern "C" int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_
   GNX_CHECK_ARG(num_classes >= 1 && num_classes <= 4096, "gnx_gemm_grouped: num_classes=%d not in [1,4096]", num_classes);
   return gemm_launch(h, nseg, segs, cls_strides, num_classes, M, N, bias, mask, ldmask, C, ldc, flags, row_index,
                      tile_info, ntiles, max_tiles, ws, ws_bytes);
+}
+
+extern "C" int32_t gnx_gemm_grouped_rows(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                                         int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
+                                         int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
+                                         const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles, void* ws,
+                                         size_t ws_bytes, int32_t tile_rows) {
+  GNX_CHECK_ARG(cls_strides && row_index && tile_info && ntiles && max_tiles > 0, "gnx_gemm_grouped_rows: NULL argument");
+  GNX_CHECK_ARG(num_classes >= 1 && num_classes <= 4096, "gnx_gemm_grouped_rows: num_classes=%d not in [1,4096]", num_classes);
+  GNX_CHECK_ARG(tile_rows == 96 || tile_rows == 128, "gnx_gemm_grouped_rows: tile_rows=%d not in {96, 128}", tile_rows);
+  return gemm_launch(h, nseg, segs, cls_strides, num_classes, M, N, bias, mask, ldmask, C, ldc, flags, row_index,
+                     tile_info, ntiles, max_tiles, ws, ws_bytes, tile_rows);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -332,9 +332,9 @@ extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
     const int k = 4 + t * per + 2 * pre;
     gnx_gemm_seg s2[2] = {seg(a->x + t * F, H, W[k], 13 * F, F), seg(a->A + (int64_t)t * 4 * F, (int64_t)T * 4 * F, a->weff[t], 4 * F, 4 * F)};
     const int64_t strides[2] = {0, (int64_t)4 * F * F};
-    GNX_TRY(gnx_gemm_grouped(h, 2, s2, strides, D, N, F, W[k + 1], nullptr, 0, a->zs[0] + t * F, H,
-                             GNX_GEMM_B_TRANS | (post > 1 ? GNX_GEMM_RELU : 0), a->dperm, a->tiles, a->ntiles, a->max_tiles,
-                             a->ws, a->ws_bytes));
+    GNX_TRY(gnx_gemm_grouped_rows(h, 2, s2, strides, D, N, F, W[k + 1], nullptr, 0, a->zs[0] + t * F, H,
+                                  GNX_GEMM_B_TRANS | (post > 1 ? GNX_GEMM_RELU : 0), a->dperm, a->tiles, a->ntiles,
+                                  a->max_tiles, a->ws, a->ws_bytes, a->tile_rows == 96 ? 96 : 128));
   }
   const int hidden_end = a->merged ? post - 1 : post;  // hidden layers 1 .. hidden_end-1 are evaluated one by one
   int zi = 0;

@@ -519,7 +519,8 @@ def _pna_forward_native(ctx, x, BE, pack, cfg, params, dc, prep):
     a = _lib.PnaFwdArgs()
     a.N, a.E, a.T, a.F, a.pre_layers, a.post_layers, a.D, a.merged = N, E, T, F, pre_layers, post_layers, D, int(merged)
     a.rowptr, a.src, a.dst, a.code = pack.rowptr.data_ptr(), pack.src.data_ptr(), pack.dst.data_ptr(), pack.code.data_ptr()
-    a.dperm, a.tiles, a.ntiles, a.max_tiles = dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(), dc.max_tiles
+    a.dperm, a.tiles, a.ntiles, a.max_tiles = dc.dperm.data_ptr(), dc.tiles_p.data_ptr(), dc.ntiles_p.data_ptr(), dc.max_tiles_p
+    a.tile_rows = dc.tile_rows_p
     a.x, a.Te = x.data_ptr(), Te.data_ptr()
     for i, w in enumerate(weffs):
         a.weff[i] = w.data_ptr()

@@ -147,7 +147,8 @@ class DegreeClasses:
     GEMM_ROWS = 128    # k_gemm's BM
     WGRAD_ROWS = 1024  # rows per weight-gradient chunk (512 -> 1024: -0.1 ms per cfg-2 step, fewer atomic flushes)
 
-    __slots__ = ("D", "dperm", "cls_ptr", "tiles", "ntiles", "max_tiles", "chunks", "nchunks", "max_chunks")
+    __slots__ = ("D", "dperm", "cls_ptr", "tiles", "ntiles", "max_tiles", "chunks", "nchunks", "max_chunks",
+                 "tiles_p", "ntiles_p", "max_tiles_p", "tile_rows_p")
 
     @staticmethod
     def build(g: "GraphPack", max_degree_hint: Optional[int] = None) -> "DegreeClasses":
@@ -178,6 +179,17 @@ class DegreeClasses:
                                   dc.ntiles.data_ptr()))
         check(lib.gnx_class_tiles(h, dc.cls_ptr.data_ptr(), dc.D, DegreeClasses.WGRAD_ROWS, dc.chunks.data_ptr(),
                                   dc.nchunks.data_ptr()))
+        # tile table of the pipelined forward product (post-layer 0): 96-row tiles where 128-row ones would leave the last
+        # round of its persistent workgroups mostly idle (gnx_gemm_tile_rows); the input-gradient product keeps `tiles`
+        dc.tile_rows_p = int(lib.gnx_gemm_tile_rows(h, g.N, 128))
+        if dc.tile_rows_p == DegreeClasses.GEMM_ROWS:
+            dc.tiles_p, dc.ntiles_p, dc.max_tiles_p = dc.tiles, dc.ntiles, dc.max_tiles
+        else:
+            dc.max_tiles_p = g.N // dc.tile_rows_p + dc.D
+            dc.tiles_p = torch.empty(3 * dc.max_tiles_p, **i32)
+            dc.ntiles_p = torch.empty(1, **i32)
+            check(lib.gnx_class_tiles(h, dc.cls_ptr.data_ptr(), dc.D, dc.tile_rows_p, dc.tiles_p.data_ptr(),
+                                      dc.ntiles_p.data_ptr()))
         return dc
 
 
@@ -343,9 +355,12 @@ GSeg = Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor, int]  # (A view
 
 
 def gemm_grouped(segs: Sequence[GSeg], out: torch.Tensor, dc: DegreeClasses, *, bias: Optional[torch.Tensor] = None,
-                 mask: Optional[torch.Tensor] = None, relu: bool = False, b_trans: bool = True) -> torch.Tensor:
+                 mask: Optional[torch.Tensor] = None, relu: bool = False, b_trans: bool = True,
+                 forward_tiles: bool = False) -> torch.Tensor:
     """gemm() over the degree-class tiles of ``dc``: A rows gathered / out rows scattered through ``dc.dperm``; segment
-    s reads its weight at ``B_s + class * stride_s`` elements (stride 0 = the same weight for every class)."""
+    s reads its weight at ``B_s + class * stride_s`` elements (stride 0 = the same weight for every class).
+    ``forward_tiles``: walk ``dc.tiles_p`` (the 96- or 128-row table of the pipelined forward product) instead of the
+    128-row table."""
     M, N = out.shape
     if M == 0:
         return out
@@ -363,6 +378,11 @@ def gemm_grouped(segs: Sequence[GSeg], out: torch.Tensor, dc: DegreeClasses, *, 
     lib, h = _lib.load(), handle(out.device)
     nbytes = lib.gnx_gemm_workspace_bytes(h, len(segs), arr, strides, dc.D, M, N, mp, flags, 1)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device) if nbytes else None
+    if forward_tiles:
+        check(lib.gnx_gemm_grouped_rows(h, len(segs), arr, strides, dc.D, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags,
+                                        dc.dperm.data_ptr(), dc.tiles_p.data_ptr(), dc.ntiles_p.data_ptr(), dc.max_tiles_p,
+                                        _ptr(ws), nbytes, dc.tile_rows_p))
+        return out
     check(lib.gnx_gemm_grouped(h, len(segs), arr, strides, dc.D, M, N, _ptr(bias), mp, ldm, cptr, ldc, flags,
                                dc.dperm.data_ptr(), dc.tiles.data_ptr(), dc.ntiles.data_ptr(), dc.max_tiles, _ptr(ws),
                                nbytes))

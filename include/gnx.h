@@ -70,7 +70,8 @@ enum {
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
   GNX_OPT_GEMM_AS = 12,          /* 1: split products with one segment, 96 < K <= 128 and N >= 256 take the activation-stationary kernel (the row tile is split once for all column tiles; bit-identical results) */
   GNX_OPT_GEMM_WS_FAST = 13,     /* 1: the weights-stationary split kernel takes its predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate (bit-identical results) */
-  GNX_OPT_COUNT = 14
+  GNX_OPT_GEMM_TILE_ROWS = 14,   /* 96 / 128: row-tile height of the pipelined tiled product (0: chosen per launch; bit-identical results) */
+  GNX_OPT_COUNT = 15
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
@@ -252,6 +253,15 @@ int32_t gnx_gemm_grouped(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, 
                          int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
                          int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
                          const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles, void* ws, size_t ws_bytes);
+/* The same over a tile table built with tile_rows = 96 or 128 (gnx_gemm_grouped assumes 128).  gnx_gemm_tile_rows: the
+ * height to build it with for M rows x N columns -- 96 where 128-row tiles would leave the last round of the persistent
+ * workgroups mostly idle (cfg-2: 640 tiles on 512 workgroup slots), else 128; results are bit-identical either way. */
+int32_t gnx_gemm_tile_rows(gnx_handle* h, int64_t M, int32_t N);
+int32_t gnx_gemm_grouped_rows(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs, const int64_t* cls_strides,
+                              int32_t num_classes, int64_t M, int32_t N, const float* bias, const float* mask,
+                              int64_t ldmask, float* C, int64_t ldc, int32_t flags, const int32_t* row_index,
+                              const int32_t* tile_info, const int32_t* ntiles, int64_t max_tiles, void* ws,
+                              size_t ws_bytes, int32_t tile_rows);
 /* per-class weight gradient: dW_cls[c] (stride dw_cls_stride) += sum over the rows of class c of dC[row]^T A[row]. */
 int32_t gnx_gemm_wgrad_grouped(gnx_handle* h, const float* dC, int64_t lddc, const float* A, int64_t lda, int64_t M,
                                int32_t N, int32_t K, float* dW_cls, int64_t lddw, int64_t dw_cls_stride,
@@ -495,7 +505,7 @@ typedef struct {
   float* out;                                  /* [N,H] */
   const int32_t* etile_info;                   /* gnx_edge_tiles table (NULL: unfused edge pipeline) */
   int32_t etile_w;                             /* its tile width */
-  int32_t _pad;
+  int32_t tile_rows;                           /* height `tiles` was built with: 96 or 128 (0 = 128); gnx_gemm_tile_rows */
 } gnx_pna_fwd_args;
 int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* args);
 

@@ -265,6 +265,51 @@ def test_activation_stationary_and_two_barrier_kernels_are_bit_identical(gpu_dev
     assert torch.equal(p, q) and not torch.isnan(p).any()
 
 
+def test_96_and_128_row_tiles_of_the_pipelined_kernel_are_bit_identical(gpu_device):
+    """k_gemm3p<.., 3> (96-row tiles: taken when 128-row tiles leave the last round of persistent workgroups mostly
+    idle) against k_gemm3p<.., 4>: the same arithmetic per row -> bit-identical, plain rows (GNX_OPT_GEMM_TILE_ROWS
+    96 / 128) and the degree-class table built with 96 rows against the 128-row one; gnx_gemm_tile_rows' choice."""
+    from gnnepcsaft_amd import ops
+    dev = torch.device("cuda:0")
+    lib, h = _lib.load(), ops.handle(dev)
+    assert lib.gnx_gemm_tile_rows(h, 81920, 128) == 96      # 640 tiles on 512 slots -> 854 tiles of 96
+    assert lib.gnx_gemm_tile_rows(h, 65536, 128) == 128     # exactly one round of 512
+    assert lib.gnx_gemm_tile_rows(h, 327680, 128) == 128    # a tie keeps 128
+    torch.manual_seed(9)
+    F = 128
+    for M in (81920, 20037):
+        x, A = torch.randn(M, F, device=gpu_device), torch.randn(M, 4 * F, device=gpu_device)
+        W, b = torch.randn(F, 5 * F, device=gpu_device) / 8, torch.randn(F, device=gpu_device)
+        outs = []
+        for rows in (96, 128):
+            ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, rows)
+            try:
+                out = torch.full((M, F), float("nan"), device=gpu_device)
+                ops.gemm([(x, None, W[:, :F]), (A, None, W[:, F:])], out, bias=b, relu=True)
+                outs.append(out)
+            finally:
+                ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 0)
+        assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0]).any()
+        ref = (torch.cat([x, A], 1).double() @ W.double().T + b.double()).relu()
+        assert rel_err(outs[0], ref) <= TOL
+    # grouped: 81 920 rows -> the forward table has 96-row tiles
+    rng = np.random.default_rng(15)
+    N, E = 81920, 163840
+    g = _pack(_graph(rng, N, E), None, None, N, None, gpu_device)
+    dc = g.degree_classes()
+    assert dc is not None and dc.tile_rows_p == 96 and dc.tiles_p is not dc.tiles
+    xg, Ag = torch.randn(N, F, device=gpu_device), torch.randn(N, 4 * F, device=gpu_device)
+    Wp = torch.randn(F, 13 * F, device=gpu_device) / 8
+    bd = torch.randn(F, device=gpu_device)
+    weff = ops.pna_weff(Wp, F, dc.D, 1.2)
+    zs = []
+    for fwd in (True, False):
+        z = torch.full((N, F), float("nan"), device=gpu_device)
+        ops.gemm_grouped([(xg, None, Wp[:, 0:F], 0), (Ag, None, weff[0], 4 * F * F)], z, dc, bias=bd, relu=True, forward_tiles=fwd)
+        zs.append(z)
+    assert torch.equal(zs[0], zs[1]) and not torch.isnan(zs[0]).any()
+
+
 def test_split_and_exact_kernels_agree(gpu_device):
     """Same call through the split-operand kernel and the exact-fp32 MFMA kernel: both within 1e-5 of fp64 and within
     2e-6 (norm-wise) of each other."""
