@@ -1854,6 +1854,156 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Mid-size product (M < 4096 rows and few 128 x 128 tiles: a 32-graph batch's 640 atoms / 1 280 bonds): the whole gnx_gemm
+// contract (segments, row scale, degree-class grouping, every epilogue) on 16 x 16 output patches, one output per thread,
+// the k-ordered fp32 fmaf chain of k_gemm_small.  The tiled kernel gives such a problem 5-10 workgroups that walk K
+// serially, two barriers per 32 k: 40 us per launch, 78 launches = 3.3 of the 4.4 ms of a cfg-1 (B = 32) step; here
+// M / 16 x N / 16 workgroups stage 128 k per barrier pair with 16-byte loads and read LDS 16 bytes at a time.
+// ---------------------------------------------------------------------------------------------------------------
+#define MID_T 16
+#define MID_KC 128
+#define MID_LD (MID_KC + 4)
+
+template <bool B_TRANS, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_mid(gemm_args g) {
+  __shared__ __attribute__((aligned(16))) float As[MID_T][MID_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[MID_T][MID_LD];  // Bs[n][k]
+  __shared__ int rid[MID_T];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int n0 = blockIdx.y * MID_T;
+  int cls = 0;
+  if (g.tile_info != nullptr) {  // a 128-row class tile = eight 16-row patches
+    const int t = blockIdx.x >> 3, sub = blockIdx.x & 7;
+    if (t >= g.ntiles[0]) return;
+    const int p0 = g.tile_info[3 * t] + MID_T * sub, pr = g.tile_info[3 * t + 1] - MID_T * sub;
+    cls = g.tile_info[3 * t + 2];
+    if (pr <= 0) return;
+    if (tid < MID_T) rid[tid] = tid < pr ? g.row_index[p0 + tid] : -1;
+  } else {
+    const int64_t m0 = (int64_t)blockIdx.x * MID_T;
+    if (tid < MID_T) rid[tid] = (m0 + tid < g.M) ? (int)(m0 + tid) : -1;
+  }
+  __syncthreads();
+
+  // chunk = 128 k of one segment; the NEXT chunk's granules are fetched into registers while this one is multiplied
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int si, int k0) {
+    const seg_dev& s = g.seg[si];
+    const float* __restrict__ sb = s.b + (int64_t)cls * s.cls_stride;
+    const bool va = s.vec_a && (s.k % 4 == 0), vb = s.vec_b && (B_TRANS ? (s.k % 4 == 0) : (g.N % 4 == 0));
+    const int kc = (s.k - k0) < MID_KC ? (s.k - k0) : MID_KC;
+    // A[rows][k0 .. k0+kc): 512 four-float granules, two per thread, consecutive threads along k
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gi = tid + 256 * j, r = gi >> 5, k4 = (gi & 31) * 4;
+      const int row = rid[r];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 0 && k4 < kc) {
+        const float* ap = s.a + (int64_t)row * s.lda + k0 + k4;
+        if (va) {
+          v = *reinterpret_cast<const f32x4*>(ap);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (k4 + e < kc) ? ap[e] : 0.f;
+        }
+        if (s.rs != nullptr) {
+          const float rs = s.rs[row];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rs * v[e];
+        }
+      }
+      ra[j] = v;
+    }
+    if (B_TRANS) {  // B[n][k]: the same shape as A
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int gi = tid + 256 * j, r = gi >> 5, k4 = (gi & 31) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + r < g.N && k4 < kc) {
+          const float* bp = sb + (int64_t)(n0 + r) * s.ldb + k0 + k4;
+          if (vb) {
+            v = *reinterpret_cast<const f32x4*>(bp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (k4 + e < kc) ? bp[e] : 0.f;
+          }
+        }
+        rb[j] = v;
+      }
+    } else {  // B[k][n]: four granules per k row, transposed into Bs[n][k] at store time
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int gi = tid + 256 * j, k = gi >> 2, c4 = (gi & 3) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kc && n0 + c4 < g.N) {
+          const float* bp = sb + (int64_t)(k0 + k) * s.ldb + n0 + c4;
+          if (vb) {
+            v = *reinterpret_cast<const f32x4*>(bp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (n0 + c4 + e < g.N) ? bp[e] : 0.f;
+          }
+        }
+        rb[j] = v;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gi = tid + 256 * j;
+      *reinterpret_cast<f32x4*>(&As[gi >> 5][(gi & 31) * 4]) = ra[j];
+      if (B_TRANS) {
+        *reinterpret_cast<f32x4*>(&Bs[gi >> 5][(gi & 31) * 4]) = rb[j];
+      } else {
+        const int k = gi >> 2, c4 = (gi & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[c4 + e][k] = rb[j][e];
+      }
+    }
+  };
+
+  float acc = 0.f;
+  int si = 0, k0 = 0;
+  fetch(0, 0);
+  while (true) {
+    stage();
+    __syncthreads();
+    const int kc = (g.seg[si].k - k0) < MID_KC ? (g.seg[si].k - k0) : MID_KC;
+    int sn = si, kn = k0 + MID_KC;
+    if (kn >= g.seg[si].k) {
+      ++sn;
+      kn = 0;
+    }
+    const bool more = sn < g.nseg;
+    if (more) fetch(sn, kn);
+    const int kend = (kc + 3) & ~3;
+    for (int k = 0; k < kend; k += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[ty][k]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[tx][k]);
+      acc = fmaf(a.x, b.x, acc);
+      acc = fmaf(a.y, b.y, acc);
+      acc = fmaf(a.z, b.z, acc);
+      acc = fmaf(a.w, b.w, acc);
+    }
+    if (!more) break;
+    __syncthreads();
+    si = sn;
+    k0 = kn;
+  }
+  const int gm = rid[ty], gn = n0 + tx;
+  if (gm >= 0 && gn < g.N) {
+    float v = acc + (g.bias != nullptr ? g.bias[gn] : 0.f);
+    float* cp = g.C + (int64_t)gm * g.ldc + gn;
+    if constexpr (EPI == EPI_ACCUM) v += *cp;
+    v = g.relu ? fmaxf(v, 0.f) : v;
+    if constexpr (EPI == EPI_MASK) v = (g.mask[(int64_t)gm * g.ldmask + gn] > 0.f) ? v : 0.f;
+    *cp = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Batched small products: up to GNX_SMALL_BATCH independent problems of k_gemm_small's kind in ONE launch (the 60-row
 // bond-table chain, the merged lin o last-post weights and their gradients for ALL layers of a model; VERDICT r2 #4:
 // ~360 launches per step, 54 of them 16 x 16-patch products of ~8 us each).  blockIdx.y = problem, blockIdx.x = output
@@ -2064,6 +2214,30 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   const int epi = mask ? EPI_MASK : ((flags & GNX_GEMM_ACCUMULATE) ? EPI_ACCUM : EPI_PLAIN);
   dim3 grid((unsigned)(tile_info ? max_tiles : gnx_cdiv(M, BM)), (unsigned)gnx_cdiv(N, BN));
   g.ny = (int)grid.y;
+  if (h->opt[GNX_OPT_GEMM_MID] != 0 && M < 4096 && gnx_cdiv(M, BM) * (int64_t)grid.y <= 48) {  // (a grouped call's
+    // max_tiles is an upper bound with one partial tile per class: the row count decides)
+    // few 128 x 128 tiles: 16 x 16 patches on many workgroups instead (see k_gemm_mid)
+    double ktot = 0.0;
+    for (int q = 0; q < nseg; ++q) ktot += g.seg[q].k;
+    gnx_prof_scope prof(h, GNX_K_GEMM_SMALL, 4.0 * M * (ktot + N) + 4.0 * N * ktot, 2.0 * (double)M * N * ktot, 0.0);
+    const dim3 gm((unsigned)(tile_info ? max_tiles * 8 : gnx_cdiv(M, MID_T)), (unsigned)gnx_cdiv(N, MID_T));
+#define GNX_LAUNCH_MID(BT)                                                                              \
+  do {                                                                                                  \
+    if (epi == EPI_MASK)                                                                                \
+      hipLaunchKernelGGL((k_gemm_mid<BT, EPI_MASK>), gm, dim3(256), 0, h->stream, g);                   \
+    else if (epi == EPI_ACCUM)                                                                          \
+      hipLaunchKernelGGL((k_gemm_mid<BT, EPI_ACCUM>), gm, dim3(256), 0, h->stream, g);                  \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_gemm_mid<BT, EPI_PLAIN>), gm, dim3(256), 0, h->stream, g);                  \
+  } while (0)
+    if (bt)
+      GNX_LAUNCH_MID(true);
+    else
+      GNX_LAUNCH_MID(false);
+#undef GNX_LAUNCH_MID
+    GNX_LAUNCH_CHECK();
+    return GNX_OK;
+  }
   // k_gemm3 / k_gemm3p: persistent workgroups, two per CU, count a multiple of 8 * ny (the XCD-aware tile walk needs it)
   auto persistent_grid = [&](unsigned row_tiles) {
     unsigned g3 = (unsigned)(gnx_cdiv((int64_t)row_tiles, 8) * 8 * grid.y);
@@ -3330,7 +3504,8 @@ __global__ void __launch_bounds__(256, 2) k_embed_bwd_mfma(embed_bwd_args g) {
 // returns GNX_OK after launching, or 1 if the shape is not eligible (caller falls back to the LDS-atomic kernel)
 int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, const int32_t* offsets, int R,
                            const float* dout, int H, float* dtable) {
-  if (K > EMB_MAX_K || (H % 4) != 0 || !aligned16(dout) || N < 4096) return 1;
+  if (K > EMB_MAX_K || (H % 4) != 0 || !aligned16(dout) || N < 256) return 1;  // (below 4096 rows the LDS-atomic kernel
+  // is contention-bound: 76 us for a 32-graph batch's 640 atoms, whose feature values repeat in every row)
   if (h->opt[GNX_OPT_EMBED_BWD_MFMA] == 0) return 1;
   embed_bwd_args g;
   g.idx = idx;

@@ -62,7 +62,7 @@ enum {
   GNX_OPT_WGRAD_VEC = 3,         /* 0: element-wise weight-gradient loaders (debug) */
   GNX_OPT_WGRAD_WGS = 4,         /* > 0: target workgroup count of the weight-gradient kernels (default: #CUs) */
   GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
-  GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 4096 */
+  GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 256 */
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
   GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
@@ -71,7 +71,8 @@ enum {
   GNX_OPT_GEMM_AS = 12,          /* 1: split products with one segment, 96 < K <= 128 and N >= 256 take the activation-stationary kernel (the row tile is split once for all column tiles; bit-identical results) */
   GNX_OPT_GEMM_WS_FAST = 13,     /* 1: the weights-stationary split kernel takes its predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate (bit-identical results) */
   GNX_OPT_GEMM_TILE_ROWS = 14,   /* 96 / 128: row-tile height of the pipelined tiled product (0: chosen per launch; bit-identical results) */
-  GNX_OPT_COUNT = 15
+  GNX_OPT_GEMM_MID = 15,         /* 1: products with M < 4096 rows and <= 48 tiles of 128 x 128 run on 16 x 16 patches (k_gemm_mid) instead of the latency-bound tiled kernel */
+  GNX_OPT_COUNT = 16
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);

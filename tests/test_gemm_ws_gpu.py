@@ -100,7 +100,7 @@ def test_gemm_ws_strided_views_and_guard_rows(gpu_device):
     assert float(out[:, :2 * F].abs().max()) == 0.0 and float(out[:, 3 * F:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("N,H", [(20000, 128), (9000, 36), (81920, 128)])
+@pytest.mark.parametrize("N,H", [(20000, 128), (9000, 36), (81920, 128), (640, 128), (300, 64)])
 def test_embed_backward_on_mfma(gpu_device, N, H):
     """Large-batch AtomEncoder backward = one-hot^T x gradient on the matrix cores (exact 0/1 products)."""
     import numpy as np

@@ -208,6 +208,91 @@ def test_gemm_segments_rowscale_strided(gpu_device):
     assert rel_err(dA, ref_dA) <= TOL
 
 
+def test_gemm_mid_size_kernel_against_the_tiled_kernel(gpu_device):
+    """k_gemm_mid (M < 4096 and <= 48 tiles of 128 x 128: 16 x 16 patches on many workgroups) against the tiled fp32-MFMA
+    kernel (GNX_OPT_GEMM_MID = 0) and fp64: a 32-graph batch's shapes (640 atoms, 1 280 bonds), multi-segment, row scale,
+    mask / accumulate, both weight layouts, unaligned views, and the degree-class grouped post-layer-0 pair."""
+    from gnnepcsaft_amd import _lib, ops
+    dev = torch.device("cuda:0")
+
+    def both(fn):
+        outs = []
+        for on in (1, 0):
+            ops.set_option(dev, _lib.OPT_GEMM_MID, on)
+            try:
+                outs.append(fn())
+            finally:
+                ops.set_option(dev, _lib.OPT_GEMM_MID, 1)
+        return outs
+
+    torch.manual_seed(19)
+    for M, N, K in [(640, 128, 128), (1280, 128, 128), (640, 128, 384), (3000, 256, 100), (515, 130, 36)]:
+        a, w, wt = torch.randn(M, K, device=gpu_device), torch.randn(K, N, device=gpu_device), torch.randn(N, K, device=gpu_device)
+        b, mask, c0 = torch.randn(N, device=gpu_device), torch.randn(M, N, device=gpu_device), torch.randn(M, N, device=gpu_device)
+
+        def nt():
+            out = torch.full((M, N), float("nan"), device=gpu_device)
+            ops.gemm([(a, None, wt)], out, bias=b, relu=True)
+            return out
+        p, q = both(nt)
+        assert rel_err(p, q) <= 2e-6 and rel_err(p, (a.double() @ wt.double().T + b.double()).relu()) <= TOL
+
+        def nn_mask():
+            out = torch.full((M, N), float("nan"), device=gpu_device)
+            ops.gemm([(a, None, w)], out, b_trans=False, mask=mask)
+            return out
+        p, q = both(nn_mask)
+        assert rel_err(p, q) <= 2e-6 and rel_err(p, (a.double() @ w.double()) * (mask > 0)) <= TOL
+
+        def nn_acc():
+            out = c0.clone()
+            ops.gemm([(a, None, w)], out, b_trans=False, accumulate=True)
+            return out
+        p, q = both(nn_acc)
+        assert rel_err(p, q) <= 2e-6 and rel_err(p, c0.double() + a.double() @ w.double()) <= TOL
+    # three segments with a row scale on strided views (the dx product's shape at 640 rows)
+    M, F = 640, 128
+    g3 = torch.randn(M, 3 * F + 8, device=gpu_device)
+    ws = [torch.randn(F, F, device=gpu_device) / 4 for _ in range(3)]
+    rs = torch.rand(M, device=gpu_device) + 0.5
+
+    def three():
+        out = torch.zeros(M, F + 8, device=gpu_device)
+        ops.gemm([(g3[:, 4:4 + F], None, ws[0]), (g3[:, 4 + F:4 + 2 * F], rs, ws[1]), (g3[:, 4 + 2 * F:4 + 3 * F], None, ws[2])],
+                 out[:, 4:4 + F], b_trans=False)
+        return out
+    p, q = both(three)
+    ref = g3[:, 4:4 + F].double() @ ws[0].double() + (rs[:, None] * g3[:, 4 + F:4 + 2 * F]).double() @ ws[1].double() + \
+        g3[:, 4 + 2 * F:4 + 3 * F].double() @ ws[2].double()
+    assert rel_err(p[:, 4:4 + F], q[:, 4:4 + F]) <= 2e-6 and rel_err(p[:, 4:4 + F], ref) <= TOL
+    assert float(p[:, :4].abs().max()) == 0.0 and float(p[:, 4 + F:].abs().max()) == 0.0
+    # grouped by in-degree class: x W0^T + A Weff(d)^T and the matching dA
+    rng = np.random.default_rng(2)
+    Nn, E = 640, 1300
+    gk = _pack(_graph(rng, Nn, E), None, None, Nn, None, gpu_device)
+    dc = gk.degree_classes()
+    assert dc is not None
+    x, A = torch.randn(Nn, F, device=gpu_device), torch.randn(Nn, 4 * F, device=gpu_device)
+    W, bd = torch.randn(F, 13 * F, device=gpu_device) / 8, torch.randn(F, device=gpu_device)
+    weff = ops.pna_weff(W, F, dc.D, 1.2)
+    amp, att = gk.degree_scalers(1.2)
+
+    def grouped():
+        z = torch.full((Nn, F), float("nan"), device=gpu_device)
+        ops.gemm_grouped([(x, None, W[:, 0:F], 0), (A, None, weff[0], 4 * F * F)], z, dc, bias=bd, relu=True)
+        return z
+    p, q = both(grouped)
+    cat = torch.cat([x, A, A * amp[:, None], A * att[:, None]], 1).double()
+    assert rel_err(p, q) <= 2e-6 and rel_err(p, (cat @ W.double().T + bd.double()).relu()) <= TOL
+
+    def grouped_da():
+        dA = torch.full((Nn, 4 * F), float("nan"), device=gpu_device)
+        ops.gemm_grouped([(x, None, weff[0], 4 * F * F)], dA, dc, b_trans=False)
+        return dA
+    p, q = both(grouped_da)
+    assert rel_err(p, q) <= 2e-6 and not torch.isnan(p).any()
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (50000, 128, 512), (60, 32, 64), (4099, 3, 32), (777, 130, 36),
                                    (200000, 64, 64)])
 def test_gemm_wgrad(gpu_device, M, N, K):
