@@ -655,6 +655,10 @@ __global__ void __launch_bounds__(512, 1) k_pna_edge_bwd(edge_bwd_args g) {
       for (int q = 0; q < 8; ++q) x[q] = wl[(k0 + q) * 128 + gc];
       split3(x, b1[s], b2[s], b3[s]);
     }
+    // consumed HERE: hipcc may otherwise sink the LDS reads above to below the barrier, where they race with the other waves'
+    // stores of the first tile (seen in k_gemm_ws3<NN>'s pipelined form)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(b1[s]), "v"(b2[s]), "v"(b3[s]));
     __syncthreads();  // the image is overwritten by the first tile
   }
   store_tile(B0, 0);

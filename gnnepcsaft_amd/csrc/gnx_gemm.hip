@@ -560,6 +560,10 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 #include "gnx_split.hpp"
 
 //
+// Round 3, measured and rejected: the split of tile t + G issued BETWEEN the MFMA slabs of tile t (two register stages of
+// loads, the k_gemm3p scheme; bit-identical): 27.4 vs 27.2 us at 81 920 rows, 42.3 vs 43.6 at 163 840, +1.5 us at 8 192
+// rows, step 6.87 vs 6.91 ms with / without the predicate-free form either way -- the split is not what bounds a tile.
+//
 // FAST (N == 128, 16-byte aligned C / mask, no accumulate): a predicate-free tile loop.  The result tile is transposed
 // 4 x 4 inside every quad of lanes (two DPP exchange stages: lane = column, four rows per register group -> lane = row,
 // four columns) and leaves as four 16-byte stores per lane, 8 full 128-byte lines per wave instruction; a partial last
@@ -662,7 +666,14 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
       }
       split3(x, b1[s], b2[s], b3[s]);
     }
-    if (!B_TRANS) __syncthreads();  // the image is overwritten by the first A tile
+    if (!B_TRANS) {
+      // the image is overwritten by the first A tile.  The fragments are CONSUMED here: hipcc may otherwise sink the LDS
+      // reads above to below this barrier (seen in the ISA of a software-pipelined form of this kernel: both barriers
+      // back to back, the reads among the first tile's split), where they race with the other waves' stores of that tile
+#pragma unroll
+      for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(b1[s]), "v"(b2[s]), "v"(b3[s]));
+      __syncthreads();
+    }
   }
 
   store_a(lds3);
@@ -3521,6 +3532,8 @@ int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, 
   int64_t chunks = gnx_cdiv(512, tiles);
   int64_t rows = gnx_cdiv(gnx_cdiv(N, chunks), BK) * BK;
   if (rows < 128) rows = 128;
+  if (N < 4096) rows = gnx_cdiv(N, (int64_t)BK) * BK;  // small batches: ONE row chunk per output tile, i.e. one adder per
+                                                       // table element -> a deterministic sum (and 20 K-steps at most)
   g.rows_per_block = rows;
   dim3 grid((unsigned)gnx_cdiv(N, rows), (unsigned)gnx_cdiv(R, BN), (unsigned)gnx_cdiv(H, BN));
   hipLaunchKernelGGL(k_embed_bwd_mfma, grid, dim3(256), 0, h->stream, g);

@@ -22,12 +22,13 @@ def _setup(conv="GINE", **kw):
     return cfg, dataset, calc_deg(dataset)
 
 
-@pytest.mark.parametrize("conv,kw,tol", [("GINE", {}, 2e-4), ("PNA", dict(pre_layers=1, post_layers=1), 2e-3)])
+@pytest.mark.parametrize("conv,kw,tol", [("GINE", {}, 2e-4), ("PNA", dict(pre_layers=1, post_layers=1), 4e-3)])
 def test_fit_tracks_the_oracle_training_trajectory(gpu_device, conv, kw, tol):
     """N optimizer steps of Trainer.fit vs N steps of the oracle model + torch.optim.AdamW(amsgrad=True, eps=1e-5) + the
     same scheduler (models.py:47-75), same initial weights, same batches in the same order: loss per step.  Tolerance:
     the first step is the forward parity (1e-5); later steps compare two fp32 training runs whose parameters drift
-    apart at the rate of their gradient differences (GINE: no discrete events; PNA pre1/post1: few)."""
+    apart at the rate of their gradient differences (GINE: no discrete events; PNA pre1/post1: few; the weight gradients
+    are summed with fp32 atomics, so the HIP run itself varies from run to run: 1.6e-3 ... 2.1e-3 seen for PNA)."""
     from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
     from gnnepcsaft_amd.train.models import create_model
     from gnnepcsaft_amd.train.trainer import DataLoader, Trainer
@@ -122,8 +123,10 @@ def test_resume_mid_epoch_continues_like_the_uninterrupted_run(gpu_device, tmp_p
     assert [r["step"] for r in trC.logged] == list(range(9, 15))
     a = [r["train_huber"] for r in trA.logged[8:]]
     c = [r["train_huber"] for r in trC.logged]
-    assert max(abs(x - y) / x for x, y in zip(a, c)) <= 1e-5, (a, c)
+    # (two runs of the SAME code differ in the last bits -- fp32 atomics in the weight gradients -- and six optimizer steps
+    # amplify that: 2e-5 of the largest parameter has been seen; a broken resume is off by percents)
+    assert max(abs(x - y) / x for x, y in zip(a, c)) <= 5e-5, (a, c)
     pa = torch.cat([p.detach().reshape(-1) for p in mA.parameters()])
     pc = torch.cat([p.detach().reshape(-1) for p in mC.parameters()])
-    assert float((pa - pc).abs().max()) <= 1e-5 * float(pa.abs().max())
+    assert float((pa - pc).abs().max()) <= 1e-4 * float(pa.abs().max())
     assert mC.model.dropout.calls == mA.model.dropout.calls == 28
