@@ -2180,7 +2180,9 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
   }
   if (tile_info == nullptr && gemm_ws_eligible(h, nseg, segs, M, N, mask, flags))
     return gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
-  if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr) {
+  if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr &&
+      h->opt[GNX_OPT_GEMM_MID] == 0) {  // (k_gemm_mid below computes the same k-ordered chain with 16-byte staging loads and
+                                        // the next chunk prefetched: 3-4 us instead of 7-10 us for a 20-row product)
     const gnx_gemm_seg& s0 = segs[0];
     dim3 grid((unsigned)gnx_cdiv(M, SM_T), (unsigned)gnx_cdiv(N, SM_T));
     gnx_prof_scope prof(h, GNX_K_GEMM_SMALL, 4.0 * (M * (double)(s0.k + N) + (double)N * s0.k), 2.0 * M * N * s0.k, 0.0);
