@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd(const float* __restrict__ d
 template <int VEC>
 __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict__ dA, const float* __restrict__ m,
                                                         const int* __restrict__ rowptr, int64_t N, int T, int F,
-                                                        float* __restrict__ dm, int centered) {
+                                                        float* __restrict__ dm, int centered, int small_deg) {
   const int H = T * F;
   const int G = H / VEC;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,6 +250,74 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
   }
   // (measured and rejected, round 2: keeping the node's first 8 messages in registers for the three passes -- 71 vs 67 us at
   // cfg-2, 0.43 vs 0.59 of HBM as run at cfg-5: the extra 32 VGPRs cost more occupancy than the L1-resident re-reads cost)
+  if (small_deg && p1 - p0 <= 4) {
+    // in-degree <= 4 (every atom of an organic molecule): the row's messages are loaded ONCE, all four loads in flight
+    // together (clamped addresses past the row's end), and the three passes run on registers -- same operations in the
+    // same order per element as the loops below
+    const int deg = p1 - p0;
+    float a[4][VEC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vload<VEC>(a[e], m + (int64_t)(p0 + (e < deg ? e : 0)) * H + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < deg) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          s[v] = __fadd_rn(s[v], a[e][v]);
+          s2[v] = __fadd_rn(s2[v], __fmul_rn(a[e][v], a[e][v]));
+          mn[v] = fminf(mn[v], a[e][v]);
+          mx[v] = fmaxf(mx[v], a[e][v]);
+        }
+      }
+    const float cnt = (float)deg;
+    float mean[VEC], sd[VEC], nmn[VEC], nmx[VEC], c2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      c2[v] = 0.f;
+      mean[v] = __fdiv_rn(s[v], cnt);
+      float mean2 = __fdiv_rn(s2[v], cnt);
+      float var = __fsub_rn(mean2, __fmul_rn(mean[v], mean[v]));
+      float o = __fsqrt_rn(fmaxf(var, STD_VAR_MIN));
+      sd[v] = (o <= STD_MASK_AT) ? 0.f : o;
+      nmn[v] = (mn[v] == 0.f) ? 1.f : 0.f;
+      nmx[v] = (mx[v] == 0.f) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < deg) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          nmn[v] += (a[e][v] == mn[v]) ? 1.f : 0.f;
+          nmx[v] += (a[e][v] == mx[v]) ? 1.f : 0.f;
+          const float dv = a[e][v] - mean[v];
+          c2[v] = fmaf(dv, dv, c2[v]);
+        }
+      }
+    float k_mean[VEC], k_mn[VEC], k_mx[VEC], k_sd[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      k_mean[v] = gmean[v] / cnt;
+      k_mn[v] = gmn[v] / nmn[v];
+      k_mx[v] = gmx[v] / nmx[v];
+      const float sdiv = (centered && c2[v] > 0.f) ? sqrtf(c2[v] / cnt) : sd[v];
+      k_sd[v] = (sd[v] > 0.f) ? gsd[v] / (cnt * sdiv) : 0.f;
+    }
+    float* dp = dm + (int64_t)p0 * H + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < deg) {
+        float o[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float r = k_mean[v] + k_sd[v] * (a[e][v] - mean[v]);
+          r += (a[e][v] == mn[v]) ? k_mn[v] : 0.f;
+          r += (a[e][v] == mx[v]) ? k_mx[v] : 0.f;
+          o[v] = r;
+        }
+        vstore<VEC>(dp + (int64_t)e * H, o);
+      }
+    return;
+  }
   const float* mp = m + (int64_t)p0 * H + c;
   for (int p = p0; p < p1; ++p, mp += H) {  // same order and roundings as k_pna_agg_fwd
     float a[VEC];
@@ -325,10 +393,12 @@ extern "C" int32_t gnx_pna_aggregate_bwd(gnx_handle* h, const float* dA, const f
     if (h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] != 0) {
       if (F % 4 == 0)
         GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd_rc<4>, dim3((unsigned)gnx_cdiv(N * (T * F / 4), 256)), dim3(256), 0,
-                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED],
+                         h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] == 1 ? 1 : 0);
       else
         GNX_LAUNCH_TIMED(prof, k_pna_agg_bwd_rc<1>, dim3((unsigned)gnx_cdiv(N * (int64_t)(T * F), 256)), dim3(256), 0,
-                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED]);
+                         h->stream, dA, m, rowptr, N, (int)T, (int)F, dm, h->opt[GNX_OPT_STD_BWD_CENTERED],
+                         h->opt[GNX_OPT_AGG_BWD_RECOMPUTE] == 1 ? 1 : 0);
       GNX_LAUNCH_CHECK();
       return GNX_OK;
     }
