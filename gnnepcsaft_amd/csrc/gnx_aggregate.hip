@@ -250,6 +250,9 @@ __global__ void __launch_bounds__(256) k_pna_agg_bwd_rc(const float* __restrict_
   }
   // (measured and rejected, round 2: keeping the node's first 8 messages in registers for the three passes -- 71 vs 67 us at
   // cfg-2, 0.43 vs 0.59 of HBM as run at cfg-5: the extra 32 VGPRs cost more occupancy than the L1-resident re-reads cost)
+  // (the same treatment of k_edge_combine_bwd's dQ gather and of k_gine_fwd / k_gine_bwd_dx -- indices, then rows, four at a time
+  // -- was measured and rejected: cfg-3 20.15-20.23 vs 19.99-20.00 ms, cfg-2 neutral; those kernels sit at 0.76 of HBM with
+  // one row in flight per thread and lose more occupancy to the 32 extra VGPRs than the loads gain)
   if (small_deg && p1 - p0 <= 4) {
     // in-degree <= 4 (every atom of an organic molecule): the row's messages are loaded ONCE, all four loads in flight
     // together (clamped addresses past the row's end), and the three passes run on registers -- same operations in the
