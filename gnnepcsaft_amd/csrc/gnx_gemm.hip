@@ -3331,11 +3331,12 @@ extern "C" int32_t gnx_gemm_wgrad_batched(gnx_handle* h, int32_t nprob, const gn
     if (i >= nprob) continue;
     const int tn = (int)gnx_cdiv(b.p[i].N, BN), tk = (int)gnx_cdiv(b.p[i].K, BN);
     const int64_t M = b.p[i].M > 0 ? b.p[i].M : 1;
-    // workgroups of the launch: at most one per CU, and at least ~4096 rows of a 128 x 128 output tile each (every
+    // workgroups of the launch: at most one per CU, and at least ~5120 rows of a 128 x 128 output tile each (every
     // workgroup ends with a 64 KB fp32 atomic flush and, on its CU, displaces the main stream's workgroups: at cfg-2's
-    // 650 k row-tiles per layer 160 workgroups beat 256 by 1.7 % of the step, at cfg-3/4/5's sizes 256 are best)
+    // 650 k row-tiles per layer 160 workgroups beat 256 by 1.7 % of the step in round 2; with round 3's shorter main
+    // stream 128 beat 160 / 96 / 192 / 256: 6.765 vs 6.836 / 6.932 / 6.880 / 6.880 ms; at cfg-3/4/5's sizes 256 are best)
     const double cus_d = (double)(h->num_cus > 0 ? h->num_cus : 256);
-    double auto_budget = total_cost / 4096.0;
+    double auto_budget = total_cost / 5120.0;
     auto_budget = auto_budget < cus_d / 4 ? cus_d / 4 : (auto_budget > cus_d ? cus_d : auto_budget);
     const double budget = h->opt[GNX_OPT_WGRAD_WGS] > 0 ? (double)h->opt[GNX_OPT_WGRAD_WGS] : auto_budget;
     int64_t chunks = (int64_t)(budget * ((double)M * tn * tk / total_cost) / (tn * tk) + 0.5);
