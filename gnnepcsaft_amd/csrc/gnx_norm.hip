@@ -57,7 +57,26 @@ __global__ void __launch_bounds__(256) k_bn_partial_v4(const float* __restrict__
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
   if (col < H) {
     const f32x4 k = *reinterpret_cast<const f32x4*>(x + col);
-    for (int64_t r = r0 + ry; r < r1; r += 8) {
+    int64_t r = r0 + ry;
+    for (; r + 24 < r1; r += 32) {  // four rows in flight (same order of additions as the one-row loop below)
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * H + col);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (r + 8) * H + col);
+      f32x4 v2 = *reinterpret_cast<const f32x4*>(x + (r + 16) * H + col);
+      f32x4 v3 = *reinterpret_cast<const f32x4*>(x + (r + 24) * H + col);
+      v0 -= k;
+      a1 += v0;
+      a2 += v0 * v0;
+      v1 -= k;
+      a1 += v1;
+      a2 += v1 * v1;
+      v2 -= k;
+      a1 += v2;
+      a2 += v2 * v2;
+      v3 -= k;
+      a1 += v3;
+      a2 += v3 * v3;
+    }
+    for (; r < r1; r += 8) {
       f32x4 v = *reinterpret_cast<const f32x4*>(x + r * H + col);
       v -= k;
       a1 += v;
@@ -94,11 +113,13 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restri
   if (col < H) {
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
-    for (int64_t r = r0 + ry; r < r1; r += 8) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * H + col);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + col);
+    auto row = [&](int64_t r, f32x4& g, f32x4& xv, f32x4& yv) {
+      g = *reinterpret_cast<const f32x4*>(dy + r * H + col);
+      xv = *reinterpret_cast<const f32x4*>(x + r * H + col);
+      yv = *reinterpret_cast<const f32x4*>((relu ? y : x) + r * H + col);  // (unconditional: keeps the loads countable)
+    };
+    auto fold = [&](f32x4 g, const f32x4& xv, const f32x4& yv) {
       if (relu) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * H + col);
         g.x = yv.x > 0.f ? g.x : 0.f;
         g.y = yv.y > 0.f ? g.y : 0.f;
         g.z = yv.z > 0.f ? g.z : 0.f;
@@ -106,6 +127,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restri
       }
       a1 += g;
       a2 += g * ((xv - mu) * rs);
+    };
+    int64_t r = r0 + ry;
+    for (; r + 8 < r1; r += 16) {  // two rows (six loads) in flight; same order of additions as the one-row loop below
+      f32x4 g0, x0, y0, g1, x1, y1;
+      row(r, g0, x0, y0);
+      row(r + 8, g1, x1, y1);
+      fold(g0, x0, y0);
+      fold(g1, x1, y1);
+    }
+    for (; r < r1; r += 8) {
+      f32x4 g, xv, yv;
+      row(r, g, xv, yv);
+      fold(g, xv, yv);
     }
   }
   s1[ry][cq] = a1;
@@ -159,7 +193,24 @@ __device__ __forceinline__ void bn_fold(const float* __restrict__ part, int64_t 
   const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
   float a1 = 0.f, a2 = 0.f;
   if (c < H) {
-    for (int64_t b = ly; b < chunks; b += 16) {
+    // four chunks' loads in flight per step (same order of additions): the one-at-a-time loop was ~20 dependent L2 round
+    // trips = 8-9 us for a kernel with no work, 16 times per step
+    int64_t b = ly;
+    for (; b + 48 < chunks; b += 64) {
+      const float p0 = part[(b * 2 + 0) * H + c], q0 = part[(b * 2 + 1) * H + c];
+      const float p1 = part[((b + 16) * 2 + 0) * H + c], q1 = part[((b + 16) * 2 + 1) * H + c];
+      const float p2 = part[((b + 32) * 2 + 0) * H + c], q2 = part[((b + 32) * 2 + 1) * H + c];
+      const float p3 = part[((b + 48) * 2 + 0) * H + c], q3 = part[((b + 48) * 2 + 1) * H + c];
+      a1 += p0;
+      a2 += q0;
+      a1 += p1;
+      a2 += q1;
+      a1 += p2;
+      a2 += q2;
+      a1 += p3;
+      a2 += q3;
+    }
+    for (; b < chunks; b += 16) {
       a1 += part[(b * 2 + 0) * H + c];
       a2 += part[(b * 2 + 1) * H + c];
     }
