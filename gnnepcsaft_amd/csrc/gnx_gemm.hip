@@ -563,6 +563,19 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 // Round 3, measured and rejected: the split of tile t + G issued BETWEEN the MFMA slabs of tile t (two register stages of
 // loads, the k_gemm3p scheme; bit-identical): 27.4 vs 27.2 us at 81 920 rows, 42.3 vs 43.6 at 163 840, +1.5 us at 8 192
 // rows, step 6.87 vs 6.91 ms with / without the predicate-free form either way -- the split is not what bounds a tile.
+#ifdef WS_STAMP  // diagnostic build only (tools/ubench/gemm_ws3_stamp.hip): phase cycle sums of wave 0 per workgroup
+__device__ unsigned long long* ws_stamp_buf = nullptr;
+#define WS_AT(i)                                     \
+  do {                                               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    const unsigned long long tn_ = clock64();        \
+    tacc[i] += tn_ - tprev;                          \
+    tprev = tn_;                                     \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+#else
+#define WS_AT(i)
+#endif
 //
 // FAST (N == 128, 16-byte aligned C / mask, no accumulate): a predicate-free tile loop.  The result tile is transposed
 // 4 x 4 inside every quad of lanes (two DPP exchange stages: lane = column, four rows per register group -> lane = row,
@@ -571,8 +584,16 @@ static hipError_t ws_launch_one(gnx_handle* h, const ws_args& g, int grid, size_
 // (past the end: the current tile again), so no branch sits between the loads of tile t + G and their first use and the
 // wait in front of the split is an exact vmcnt(stores issued since) -- with the predicated 4-byte epilogue hipcc could
 // not count the stores and drained ALL of them (write acknowledgements, ~1 us) before every split.
-template <bool B_TRANS, int EPI, bool FAST>
-__global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
+// NW = waves per workgroup: 8 (64-row tiles, one workgroup per CU) or 4 (32-row tiles, TWO workgroups per CU with their
+// own barriers, so that one can issue loads / stores while the other multiplies: in-kernel stamps of the 8-wave form give
+// a tile 6.2 k cycles = loads 0.8 k + fragment reads and 48 MFMAs 2.2 k + epilogue 1.2 k + split 0.7 k + barrier 1.3 k, all
+// eight waves in the same phase -- tools/ubench/gemm_ws3_stamp.hip).  The same arithmetic per row either way.
+template <bool B_TRANS, int EPI, bool FAST, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_gemm_ws3(ws_args g) {
+  constexpr int RS = 2 * NW;               // rows per loader pass (32 lanes per row)
+  constexpr int TM = 4 * RS;               // rows per tile: 64 / 32
+  constexpr int PIECE = TM * W3_LDB;       // one bf16 image of a tile
+  constexpr int BUF = 3 * PIECE;           // the three images
   extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -590,11 +611,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   f32x4 ra[4];
   int okmask = 0;
   auto load_a = [&](int tile) {
-    const int64_t m0 = (int64_t)tile * W3_BM;
+    const int64_t m0 = (int64_t)tile * TM;
     okmask = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t gm = m0 + ar + 16 * i;
+      const int64_t gm = m0 + ar + RS * i;
       ra[i] = *reinterpret_cast<const f32x4*>(g.A + (gm < g.M ? gm : g.M - 1) * g.lda + akc);
       okmask |= (ak_ok && (FAST || gm < g.M)) ? (1 << i) : 0;  // FAST: rows past the end repeat row M - 1
     }
@@ -602,7 +623,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;  // 8-byte LDS word (four bf16)
   auto store_a = [&](unsigned char* buf) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // rows ar + 32 h and ar + 32 h + 16: four k each -> one split3 of 8 values
+    for (int h = 0; h < 2; ++h) {  // rows ar + 2 RS h and ar + 2 RS h + RS: four k each -> one split3 of 8 values
       float x[8];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -613,9 +634,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(&pc[p]);
-        unsigned char* q = buf + p * W3_PIECE + (ar + 32 * h) * W3_LDB + ak * 2;
+        unsigned char* q = buf + p * PIECE + (ar + 2 * RS * h) * W3_LDB + ak * 2;
         *reinterpret_cast<f32x2*>(q) = f32x2{w.x, w.y};
-        *reinterpret_cast<f32x2*>(q + 16 * W3_LDB) = f32x2{w.z, w.w};
+        *reinterpret_cast<f32x2*>(q + RS * W3_LDB) = f32x2{w.z, w.w};
       }
     }
   };
@@ -637,8 +658,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
       const int r = tid >> 5, c4 = (tid & 31) * 4;
       const bool c_ok = c4 < g.N;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rr = r + 16 * i;
+      for (int i = 0; i < 128 / RS; ++i) {
+        const int rr = r + RS * i;
         f32x4 v = *reinterpret_cast<const f32x4*>(g.B + (int64_t)(rr < g.K ? rr : 0) * g.ldb + (c_ok ? c4 : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(wl + rr * 128 + c4) = (c_ok && rr < g.K) ? v : z;
@@ -695,6 +716,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
   using XOR1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]
   using XOR2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]
 
+#ifdef WS_STAMP
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = clock64();
+  int ntile_done = 0;
+#endif
   while (tile < g.ntiles) {
     const int next = tile + gridDim.x;
     const bool has_next = next < g.ntiles;
@@ -704,7 +730,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
     } else if (has_next) {
       load_a(next);
     }
-    const int64_t m0 = (int64_t)tile * W3_BM;
+    const int64_t m0 = (int64_t)tile * TM;
 
     f32x16 acc, corr;
 #pragma unroll
@@ -712,13 +738,14 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
       acc[r] = 0.f;
       corr[r] = 0.f;
     }
-    const unsigned char* ap = lds3 + cur * W3_BUF + (wr + li) * W3_LDB + 16 * lh;
+    const unsigned char* ap = lds3 + cur * BUF + (wr + li) * W3_LDB + 16 * lh;
+    WS_AT(0);  // issue of the next tile's loads
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < nslab) {
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * s);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + W3_PIECE);
-        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + 2 * W3_PIECE);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + PIECE);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ap + 32 * s + 2 * PIECE);
         corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[s], corr, 0, 0, 0);
         corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[s], corr, 0, 0, 0);
         corr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[s], corr, 0, 0, 0);
@@ -729,6 +756,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += corr[r];
+    WS_AT(1);  // fragment reads + 48 MFMAs
 
     if constexpr (FAST) {
       const int64_t rbase = m0 + wr + 4 * lh + qj, rlast = g.M - 1;
@@ -756,7 +784,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
         const int64_t gr = rbase + 8 * gq < rlast ? rbase + 8 * gq : rlast;
         *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + colq) = v;
       }
-    } else if (m0 + W3_BM <= g.M) {
+    } else if (m0 + TM <= g.M) {
       epilogue_tile_full<EPI>(acc, m0 + wr + 4 * lh, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
     } else {
       int rows[16];
@@ -768,11 +796,23 @@ __global__ void __launch_bounds__(512, 1) k_gemm_ws3(ws_args g) {
       epilogue_tile<EPI>(acc, rows, gc, g.N, bv, g.relu, g.mask, g.ldmask, g.C, g.ldc);
     }
 
-    if (has_next) store_a(lds3 + (cur ^ 1) * W3_BUF);
+    WS_AT(2);  // epilogue (transpose + stores)
+    if (has_next) store_a(lds3 + (cur ^ 1) * BUF);
+    WS_AT(3);  // wait for the next tile's loads + split + LDS stores
     __syncthreads();
+    WS_AT(4);  // barrier
     cur ^= 1;
     tile = next;
+#ifdef WS_STAMP
+    ++ntile_done;
+#endif
   }
+#ifdef WS_STAMP
+  if (tid == 0 && ws_stamp_buf != nullptr) {
+    for (int i = 0; i < 5; ++i) ws_stamp_buf[(size_t)blockIdx.x * 8 + i] = tacc[i];
+    ws_stamp_buf[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)ntile_done;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1727,16 +1767,18 @@ static hipError_t as3_launch_one(gnx_handle* h, const gemm_args& g, unsigned gri
   return hipSuccess;
 }
 
-template <bool BT, int EPI, bool FAST>
+template <bool BT, int EPI, bool FAST, int NW>
 static hipError_t ws3_launch_fast(gnx_handle* h, const ws_args& g, int grid) {
+  // LDS: two stages of a TM-row tile, and at least the 64 KB the NN weight staging image needs
+  constexpr size_t lds = (NW == 8) ? (size_t)(2 * W3_BUF) : (size_t)(64 * 1024);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws3<BT, EPI, FAST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ws3<BT, EPI, FAST, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NW == 8 ? 160 * 1024 : 64 * 1024));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm_ws3<BT, EPI, FAST>), dim3(grid), dim3(512), 2 * W3_BUF, h->stream, g);
+  hipLaunchKernelGGL((k_gemm_ws3<BT, EPI, FAST, NW>), dim3(grid), dim3(64 * NW), lds, h->stream, g);
   return hipGetLastError();
 }
 
@@ -1745,8 +1787,17 @@ static hipError_t ws3_launch_one(gnx_handle* h, const ws_args& g, int grid) {
   // the predicate-free kernel: all 128 columns, 16-byte stores (and mask loads), no read-modify-write of C
   const bool fast = h->opt[GNX_OPT_GEMM_WS_FAST] != 0 && EPI != EPI_ACCUM && g.N == 128 && aligned16(g.C) && g.ldc % 4 == 0 &&
                     (g.mask == nullptr || (aligned16(g.mask) && g.ldmask % 4 == 0));
-  if (EPI != EPI_ACCUM && fast) return ws3_launch_fast<BT, EPI, EPI != EPI_ACCUM>(h, g, grid);
-  return ws3_launch_fast<BT, EPI, false>(h, g, grid);
+  if (EPI != EPI_ACCUM && fast) {
+    if (h->opt[GNX_OPT_GEMM_WS_FAST] == 2) {  // two 4-wave workgroups per CU on 32-row tiles
+      ws_args g2 = g;
+      g2.ntiles = (int)gnx_cdiv(g.M, (int64_t)32);
+      const int cus = h->num_cus > 0 ? h->num_cus : 256;
+      const int grid2 = g2.ntiles < 2 * cus ? g2.ntiles : 2 * cus;
+      return ws3_launch_fast<BT, EPI, EPI != EPI_ACCUM, 4>(h, g2, grid2);
+    }
+    return ws3_launch_fast<BT, EPI, EPI != EPI_ACCUM, 8>(h, g, grid);
+  }
+  return ws3_launch_fast<BT, EPI, false, 8>(h, g, grid);
 }
 
 static int32_t gemm_ws_launch(gnx_handle* h, const gnx_gemm_seg& s, int64_t M, int32_t N, const float* bias,

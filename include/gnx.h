@@ -69,7 +69,7 @@ enum {
   GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd / _bwd take the fused edge kernels (gnx_pna_edge_fwd / gnx_pna_edge_bwd) when eligible (bit-identical messages, h1, aggregate, gh1, dP); 2: forward only; 0: three launches each */
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */
   GNX_OPT_GEMM_AS = 12,          /* 1: split products with one segment, 96 < K <= 128 and N >= 256 take the activation-stationary kernel (the row tile is split once for all column tiles; bit-identical results) */
-  GNX_OPT_GEMM_WS_FAST = 13,     /* 1: the weights-stationary split kernel takes its predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate (bit-identical results) */
+  GNX_OPT_GEMM_WS_FAST = 13,     /* the weights-stationary split kernel's predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate: 2 = as two 4-wave workgroups per CU on 32-row tiles (default), 1 = one 8-wave workgroup per CU on 64-row tiles, 0 = the predicated kernel; bit-identical results */
   GNX_OPT_GEMM_TILE_ROWS = 14,   /* 96 / 128: row-tile height of the pipelined tiled product (0: chosen per launch; bit-identical results) */
   GNX_OPT_GEMM_MID = 15,         /* 1: products with M < 4096 rows and <= 48 tiles of 128 x 128 run on 16 x 16 patches (k_gemm_mid) instead of the latency-bound tiled kernel */
   GNX_OPT_COUNT = 16

@@ -41,6 +41,7 @@ VARIANTS = {
     "nofusedbwd": lambda dev: ops.set_option(dev, _lib.OPT_EDGE_FUSED, 2),
     "noas3": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_AS, 0),
     "nowsfast": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 0),
+    "ws8waves": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1),
     "rcloop": lambda dev: ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 2),
     "rows128": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 128),
     "rows96": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 96),
@@ -55,7 +56,7 @@ def reset(dev):
     ops.set_option(dev, _lib.OPT_EDGE_FUSED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_AS, 1)
     ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 1)
-    ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1)
+    ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 2)
     ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 0)
     ops.set_option(dev, _lib.OPT_WGRAD_WGS, 0); ops.DegreeClasses.WGRAD_ROWS = 1024; ops.set_wgrad_batching(True)
     for k, v in EXTRA_RESET.items():

@@ -3,9 +3,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnepcsaft_amd import _lib, ops
 dev = torch.device("cuda:0")
-if len(sys.argv) > 1:  # e.g. "nofast": the predicated epilogue (GNX_OPT_GEMM_WS_FAST = 0)
-    ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 0)
-    print("predicated epilogue")
+if len(sys.argv) > 1:  # GNX_OPT_GEMM_WS_FAST: 0 = predicated epilogue, 1 = predicate-free 8-wave form, 2 (default) = 4-wave form
+    ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, int(sys.argv[1]))
+    print("GNX_OPT_GEMM_WS_FAST =", sys.argv[1])
 w = torch.randn(128, 128, device=dev)
 for M in (8192, 16384, 32768, 65536, 81920, 163840, 327680):
     a = torch.randn(M, 128, device=dev); out = torch.empty(M, 128, device=dev)
