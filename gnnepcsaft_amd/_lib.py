@@ -14,7 +14,7 @@ ABI_VERSION = 3
 GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, -4
 # gnx_set_option ids (include/gnx.h)
 OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
-    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS, OPT_GEMM_AS, OPT_GEMM_WS_FAST, OPT_GEMM_TILE_ROWS, OPT_GEMM_MID = range(16)
+    OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS, OPT_GEMM_AS, OPT_GEMM_WS_FAST, OPT_GEMM_TILE_ROWS, OPT_GEMM_MID, OPT_SPLIT_AHEAD = range(17)
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \

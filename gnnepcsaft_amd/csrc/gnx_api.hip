@@ -51,7 +51,7 @@ extern "C" int32_t gnx_create(gnx_handle** out, int32_t device) {
               {GNX_OPT_WGRAD_PIPE, "GNX_WGRAD_PIPE", 1},       {GNX_OPT_EDGE_FUSED, "GNX_EDGE_FUSED", 1},
               {GNX_OPT_SIDE_CUS, "GNX_SIDE_CUS", 0},           {GNX_OPT_GEMM_AS, "GNX_GEMM_AS", 1},
               {GNX_OPT_GEMM_WS_FAST, "GNX_GEMM_WS_FAST", 2},   {GNX_OPT_GEMM_TILE_ROWS, "GNX_GEMM_TILE_ROWS", 0},
-              {GNX_OPT_GEMM_MID, "GNX_GEMM_MID", 1}};
+              {GNX_OPT_GEMM_MID, "GNX_GEMM_MID", 1},           {GNX_OPT_SPLIT_AHEAD, "GNX_SPLIT_AHEAD", 1}};
   for (const auto& o : opts) {
     const char* e = getenv(o.env);
     h->opt[o.id] = e ? atoi(e) : o.def;

@@ -19,10 +19,10 @@ struct gnx_handle {
   float* d_scratch = nullptr;  // 4 KiB
   float* d_zero = nullptr;     // 256 zero bytes, never written: what a masked-out vector load reads
   // side streams (gnx_side_begin/end/join): created on first use; `stream` is swapped to one between begin and end
-  static constexpr int kSideStreams = 2;
-  hipStream_t side[kSideStreams] = {nullptr, nullptr};
+  static constexpr int kSideStreams = 3;  // 0: weight gradients, 1: bond-table chain, 2: weight-image splits ahead of their products
+  hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
   hipStream_t main_saved = nullptr;
-  hipEvent_t side_fork[kSideStreams] = {nullptr, nullptr}, side_done[kSideStreams] = {nullptr, nullptr};
+  hipEvent_t side_fork[kSideStreams] = {nullptr, nullptr, nullptr}, side_done[kSideStreams] = {nullptr, nullptr, nullptr};
   bool on_side = false;
   // A/B switches (gnx_set_option); initialised ONCE from the GNX_* environment variables in gnx_create
   int opt[GNX_OPT_COUNT] = {};

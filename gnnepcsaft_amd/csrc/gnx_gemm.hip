@@ -2229,8 +2229,10 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     GNX_CHECK_ARG(in.lda >= in.k, "gnx_gemm: segment %d: lda < k", s);
     GNX_CHECK_ARG(bt ? in.ldb >= in.k : in.ldb >= N, "gnx_gemm: segment %d: ldb too small", s);
   }
+  const bool split_only = (flags & GNX_GEMM_SPLIT_ONLY) != 0;  // only the weight images (if this call uses any) are written
   if (tile_info == nullptr && gemm_ws_eligible(h, nseg, segs, M, N, mask, flags))
-    return gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
+    return split_only ? GNX_OK : gemm_ws_launch(h, segs[0], M, N, bias, mask, ldmask, C, ldc, flags);
+  if (split_only && M < 4096) return GNX_OK;  // (no split path below 4096 rows)
   if (tile_info == nullptr && nseg == 1 && M <= 256 && mask == nullptr && segs[0].rowscale == nullptr &&
       h->opt[GNX_OPT_GEMM_MID] == 0) {  // (k_gemm_mid below computes the same k-ordered chain with 16-byte staging loads and
                                         // the next chunk prefetched: 3-4 us instead of 7-10 us for a 20-row product)
@@ -2359,16 +2361,23 @@ static int32_t gemm_launch(gnx_handle* h, int32_t nseg, const gnx_gemm_seg* segs
     sa.frag = (pipe || as3) ? 1 : 0;
     sa.out = reinterpret_cast<__bf16*>(ws);
     const int64_t items = (int64_t)sa.D * sa.Npad * (sa.Kpad / 8);
-    if (bt)
+    if (flags & GNX_GEMM_PRESPLIT) {
+      // the caller ran this very split before (GNX_GEMM_SPLIT_ONLY, same arguments)
+    } else if (bt)
       hipLaunchKernelGGL(k_split_weights<true>, dim3((unsigned)gnx_cdiv(items, 256)), dim3(256), 0, h->stream, sa);
     else
       hipLaunchKernelGGL(k_split_weights<false>, dim3((unsigned)gnx_cdiv(items, 256)), dim3(256), 0, h->stream, sa);
+    if (split_only) {
+      GNX_LAUNCH_CHECK();
+      return GNX_OK;
+    }
     g.bsplit = sa.out;
     g.Npad = sa.Npad;
     g.Kpad = sa.Kpad;
     for (int q = 0; q < MAX_SEGS; ++q) g.koff[q] = sa.koff[q];
     g.steps = sa.Kpad / BK;
   }
+  if (split_only) return GNX_OK;  // (this call takes a kernel that needs no images)
 #define GNX_LAUNCH_GEMM(BT, EPI)                                                          \
   do {                                                                                    \
     if (split) {                                                                          \

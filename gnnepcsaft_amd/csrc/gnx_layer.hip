@@ -79,14 +79,24 @@ int32_t on_side(gnx_handle* h, int which, bool enabled, F body) {
 
 // upper bound of the split-weight images any product of the layer's forward or backward needs (gnx_gemm_workspace_bytes): the
 // degree-class product dA = g Weff(d) (D classes, N = 4F, K = F) and the 3-segment dx product (N = F, K = 3F)
-extern "C" size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D) {
+// Layout of the workspace: [0, scratch) is reused by every product of the layer in turn; behind it one region per tower and
+// per tiled product whose weight images are split AHEAD on side stream 2 (GNX_OPT_SPLIT_AHEAD): forward: post-layer 0;
+// backward: dA and dx.
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static void pna_ws_sizes(int32_t T, int32_t F, int32_t D, size_t& scratch, size_t& post0, size_t& grouped, size_t& dx) {
   auto pad = [](int64_t v, int64_t m) { return (v + m - 1) / m * m; };
-  const size_t grouped = (size_t)(D > 0 ? D : 1) * 3 * pad(4 * (int64_t)F, 128) * pad(F, 32) * 2;
-  const size_t dx = (size_t)3 * pad(F, 128) * (3 * pad(F, 32)) * 2;
+  grouped = align256((size_t)(D > 0 ? D : 1) * 3 * pad(4 * (int64_t)F, 128) * pad(F, 32) * 2);
+  dx = align256((size_t)3 * pad(F, 128) * (3 * pad(F, 32)) * 2);
   const size_t lin = (size_t)3 * pad((int64_t)T * F, 128) * pad((int64_t)T * F, 32) * 2;  // lin / merged product, H x H
   // forward: post-layer 0 by degree class, z = x W0^T + A Weff(d)^T  (N = F, K = F + 4F)
-  const size_t post0 = (size_t)(D > 0 ? D : 1) * 3 * pad(F, 128) * (pad(F, 32) + pad(4 * (int64_t)F, 32)) * 2;
-  return std::max(std::max(grouped, post0), std::max(dx, lin)) + 256;
+  post0 = align256((size_t)(D > 0 ? D : 1) * 3 * pad(F, 128) * (pad(F, 32) + pad(4 * (int64_t)F, 32)) * 2);
+  scratch = align256(std::max(std::max(grouped, post0), std::max(dx, lin)) + 256);
+}
+
+extern "C" size_t gnx_pna_conv_bwd_workspace_bytes(int32_t T, int32_t F, int32_t D) {
+  size_t scratch, post0, grouped, dx;
+  pna_ws_sizes(T, F, D, scratch, post0, grouped, dx);
+  return scratch + (size_t)(T > 0 ? T : 1) * std::max(post0, grouped + dx);
 }
 
 extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
@@ -105,6 +115,42 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   float* const* G = a->grads;
   const float* lin_w = P[2];
   WgradQueue wq;
+
+  // the weight images of the two tiled products of this backward (dA per degree class, the 3-segment dx) are split on side
+  // stream 2 while the lin / hidden input-gradient products run; the products take them as they are (GNX_GEMM_PRESPLIT)
+  size_t scratch = a->ws_bytes, r_post0 = 0, r_dA = 0, r_dx = 0;
+  bool ahead = (h->opt[GNX_OPT_SPLIT_AHEAD] == 2 || (h->opt[GNX_OPT_SPLIT_AHEAD] == 1 && T >= 2)) && a->use_side_streams != 0 &&
+               !h->on_side && N >= 4096 && a->ws != nullptr;
+  if (ahead) {
+    pna_ws_sizes(T, F, D, scratch, r_post0, r_dA, r_dx);
+    ahead = scratch + (size_t)T * (r_dA + r_dx) <= a->ws_bytes;
+    if (!ahead) scratch = a->ws_bytes;
+  }
+  unsigned char* const ahead_base = reinterpret_cast<unsigned char*>(a->ws) + scratch;
+  auto dA_call = [&](int t, const float* gt, int extra_flags, void* ws, size_t ws_bytes) -> int32_t {
+    gnx_gemm_seg s = seg(gt, H, a->weff[t], 4 * F, F);
+    const int64_t stride = (int64_t)4 * F * F;
+    return gnx_gemm_grouped(h, 1, &s, &stride, D, N, 4 * F, nullptr, nullptr, 0, a->dA + (int64_t)t * 4 * F, (int64_t)T * 4 * F,
+                            extra_flags, a->dperm, a->tiles, a->ntiles, a->max_tiles, ws, ws_bytes);
+  };
+  auto dx_call = [&](int t, const float* g_post0, int extra_flags, void* ws, size_t ws_bytes) -> int32_t {
+    const int k0 = pidx(t, true, 0), kp = pidx(t, false, 0);
+    const float* W0 = P[k0];
+    gnx_gemm_seg s3[3] = {seg(g_post0 + t * F, H, P[kp], 13 * F, F), seg(a->dP + t * F, H, W0, 3 * F, F),
+                          seg(a->dQ + t * F, H, W0 + F, 3 * F, F)};
+    return gnx_gemm(h, 3, s3, N, F, nullptr, nullptr, 0, a->dx + t * F, H, extra_flags, ws, ws_bytes);
+  };
+  if (ahead) {
+    GNX_TRY(gnx_side_begin_n(h, 2));
+    int32_t st = GNX_OK;
+    for (int t = 0; t < T && st == GNX_OK; ++t) {  // (gbuf[0] stands in for the gradient operand: only its alignment matters)
+      unsigned char* reg = ahead_base + (size_t)t * (r_dA + r_dx);
+      st = dA_call(t, a->gbuf[0] + t * F, GNX_GEMM_SPLIT_ONLY, reg, r_dA);
+      if (st == GNX_OK) st = dx_call(t, a->gbuf[0], GNX_GEMM_SPLIT_ONLY, reg + r_dA, r_dx);
+    }
+    (void)gnx_side_end(h);
+    GNX_TRY(st);
+  }
 
   // ---- lin (or lin o last post layer): dgrad into gbuf[0]
   // every gradient buffer of the chain is distinct: the queued weight-gradient problems read them at flush time
@@ -154,10 +200,12 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
                                      a->chunks, a->nchunks, a->max_chunks));
       return defer ? GNX_OK : gnx_pna_weff_bwd(h, dWeff, F, D, a->avg_deg_log, dWp, 13 * F);
     }));
-    gnx_gemm_seg s = seg(gt, H, a->weff[t], 4 * F, F);
-    const int64_t stride = (int64_t)4 * F * F;
-    GNX_TRY(gnx_gemm_grouped(h, 1, &s, &stride, D, N, 4 * F, nullptr, nullptr, 0, a->dA + (int64_t)t * 4 * F,
-                             (int64_t)T * 4 * F, 0, a->dperm, a->tiles, a->ntiles, a->max_tiles, a->ws, a->ws_bytes));
+    if (ahead) {
+      if (t == 0) GNX_TRY(gnx_side_join_n(h, 2));
+      GNX_TRY(dA_call(t, gt, GNX_GEMM_PRESPLIT, ahead_base + (size_t)t * (r_dA + r_dx), r_dA));
+    } else {
+      GNX_TRY(dA_call(t, gt, 0, a->ws, scratch));
+    }
   }
   const float* g_post0 = g;  // gradient w.r.t. post-layer 0's output: also an operand of dx below
   // ---- scatter-aggregate backward, then the pre layers last..1
@@ -196,14 +244,13 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     GNX_TRY(gnx_edge_combine_bwd(h, ge, a->rowptr, a->colptr, a->cpos, a->code, N, E, H, 0, a->dP, a->dQ, nullptr, nullptr, 0));
   }
   for (int t = 0; t < T; ++t) {
-    const int k0 = pidx(t, true, 0), kp = pidx(t, false, 0);
-    const float* W0 = P[k0];
-    float* dW0 = G[k0];
+    float* dW0 = G[pidx(t, true, 0)];
     wq.add(a->dP + t * F, H, a->x + t * F, H, N, F, F, dW0, 3 * F, nullptr);
     wq.add(a->dQ + t * F, H, a->x + t * F, H, N, F, F, dW0 + F, 3 * F, nullptr);
-    gnx_gemm_seg s3[3] = {seg(g_post0 + t * F, H, P[kp], 13 * F, F), seg(a->dP + t * F, H, W0, 3 * F, F),
-                          seg(a->dQ + t * F, H, W0 + F, 3 * F, F)};
-    GNX_TRY(gnx_gemm(h, 3, s3, N, F, nullptr, nullptr, 0, a->dx + t * F, H, 0, a->ws, a->ws_bytes));
+    if (ahead)
+      GNX_TRY(dx_call(t, g_post0, GNX_GEMM_PRESPLIT, ahead_base + (size_t)t * (r_dA + r_dx) + r_dA, r_dx));
+    else
+      GNX_TRY(dx_call(t, g_post0, 0, a->ws, scratch));
   }
   // ---- bond-table gradient chain on side stream 1 (feeds parameter gradients and the shared accumulator only)
   GNX_TRY(on_side(h, 1, side, [&]() -> int32_t {
@@ -297,11 +344,41 @@ extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
   GNX_CHECK_ARG(a->params && a->x && a->Te && a->P && a->Q && a->A && a->out, "gnx_pna_conv_fwd: NULL array");
   const int per = 2 * (pre + post);
   const float* const* W = a->params;
+  // post-layer 0's weight images (x part + Weff(d), per tower) are split on side stream 2 while the node products and the
+  // edge pipeline run; the product then takes them as they are (GNX_GEMM_PRESPLIT)
+  const int post0_flags = GNX_GEMM_B_TRANS | (post > 1 ? GNX_GEMM_RELU : 0);
+  const int post0_rows = a->tile_rows == 96 ? 96 : 128;
+  size_t scratch = a->ws_bytes, r_post0 = 0, r_grouped = 0, r_dx = 0;
+  // (measured: cfg-5, four towers = twelve splits per layer: -0.44 ms per step; cfg-2, one tower: +0.02 ms -- the fork / join
+  // events cost what the three 7-us splits saved -- so: 1 = with two or more towers, 2 = always, 0 = never)
+  bool ahead = (h->opt[GNX_OPT_SPLIT_AHEAD] == 2 || (h->opt[GNX_OPT_SPLIT_AHEAD] == 1 && T >= 2)) && !h->on_side && N >= 4096 &&
+               a->ws != nullptr;
+  if (ahead) {
+    pna_ws_sizes(T, F, D, scratch, r_post0, r_grouped, r_dx);
+    ahead = scratch + (size_t)T * r_post0 <= a->ws_bytes;
+    if (!ahead) scratch = a->ws_bytes;
+  }
+  unsigned char* const ahead_base = reinterpret_cast<unsigned char*>(a->ws) + scratch;
+  auto post0_call = [&](int t, int extra_flags, void* ws, size_t ws_bytes) -> int32_t {
+    const int k = 4 + t * per + 2 * pre;
+    gnx_gemm_seg s2[2] = {seg(a->x + t * F, H, W[k], 13 * F, F),
+                          seg(a->A + (int64_t)t * 4 * F, (int64_t)T * 4 * F, a->weff[t], 4 * F, 4 * F)};
+    const int64_t strides[2] = {0, (int64_t)4 * F * F};
+    return gnx_gemm_grouped_rows(h, 2, s2, strides, D, N, F, W[k + 1], nullptr, 0, a->zs[0] + t * F, H, post0_flags | extra_flags,
+                                 a->dperm, a->tiles, a->ntiles, a->max_tiles, ws, ws_bytes, post0_rows);
+  };
+  if (ahead) {
+    GNX_TRY(gnx_side_begin_n(h, 2));
+    int32_t st = GNX_OK;
+    for (int t = 0; t < T && st == GNX_OK; ++t) st = post0_call(t, GNX_GEMM_SPLIT_ONLY, ahead_base + (size_t)t * r_post0, r_post0);
+    (void)gnx_side_end(h);
+    GNX_TRY(st);
+  }
   for (int t = 0; t < T; ++t) {
     const float* W0 = W[4 + t * per];
     gnx_gemm_seg sp = seg(a->x + t * F, H, W0, 3 * F, F), sq = seg(a->x + t * F, H, W0 + F, 3 * F, F);
-    GNX_TRY(gnx_gemm(h, 1, &sp, N, F, nullptr, nullptr, 0, a->P + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
-    GNX_TRY(gnx_gemm(h, 1, &sq, N, F, nullptr, nullptr, 0, a->Q + t * F, H, GNX_GEMM_B_TRANS, a->ws, a->ws_bytes));
+    GNX_TRY(gnx_gemm(h, 1, &sp, N, F, nullptr, nullptr, 0, a->P + t * F, H, GNX_GEMM_B_TRANS, a->ws, scratch));
+    GNX_TRY(gnx_gemm(h, 1, &sq, N, F, nullptr, nullptr, 0, a->Q + t * F, H, GNX_GEMM_B_TRANS, a->ws, scratch));
   }
   // edge pipeline: message assembly -> pre layers 1.. -> scatter-aggregate.  With two pre layers (the reference's default)
   // it is ONE launch (gnx_pna_edge_fwd: h1 and the messages are written once and never read back, bit-identical results)
@@ -324,17 +401,16 @@ extern "C" int32_t gnx_pna_conv_fwd(gnx_handle* h, const gnx_pna_fwd_args* a) {
         const int k = 4 + t * per + 2 * i;
         gnx_gemm_seg s = seg(a->hs[i - 1] + t * F, H, W[k], F, F);
         GNX_TRY(gnx_gemm(h, 1, &s, E, F, W[k + 1], nullptr, 0, a->hs[i] + t * F, H,
-                         GNX_GEMM_B_TRANS | (i < pre - 1 ? GNX_GEMM_RELU : 0), a->ws, a->ws_bytes));
+                         GNX_GEMM_B_TRANS | (i < pre - 1 ? GNX_GEMM_RELU : 0), a->ws, scratch));
       }
     GNX_TRY(gnx_pna_aggregate_fwd(h, a->hs[pre - 1], a->rowptr, N, E, T, F, a->A));
   }
+  if (ahead) GNX_TRY(gnx_side_join_n(h, 2));
   for (int t = 0; t < T; ++t) {
-    const int k = 4 + t * per + 2 * pre;
-    gnx_gemm_seg s2[2] = {seg(a->x + t * F, H, W[k], 13 * F, F), seg(a->A + (int64_t)t * 4 * F, (int64_t)T * 4 * F, a->weff[t], 4 * F, 4 * F)};
-    const int64_t strides[2] = {0, (int64_t)4 * F * F};
-    GNX_TRY(gnx_gemm_grouped_rows(h, 2, s2, strides, D, N, F, W[k + 1], nullptr, 0, a->zs[0] + t * F, H,
-                                  GNX_GEMM_B_TRANS | (post > 1 ? GNX_GEMM_RELU : 0), a->dperm, a->tiles, a->ntiles,
-                                  a->max_tiles, a->ws, a->ws_bytes, a->tile_rows == 96 ? 96 : 128));
+    if (ahead)
+      GNX_TRY(post0_call(t, GNX_GEMM_PRESPLIT, ahead_base + (size_t)t * r_post0, r_post0));
+    else
+      GNX_TRY(post0_call(t, 0, a->ws, scratch));
   }
   const int hidden_end = a->merged ? post - 1 : post;  // hidden layers 1 .. hidden_end-1 are evaluated one by one
   int zi = 0;

@@ -72,7 +72,8 @@ enum {
   GNX_OPT_GEMM_WS_FAST = 13,     /* the weights-stationary split kernel's predicate-free form (quad-transposed 16-byte stores, exact waits) for N = 128, aligned operands, no accumulate: 2 = as two 4-wave workgroups per CU on 32-row tiles (default), 1 = one 8-wave workgroup per CU on 64-row tiles, 0 = the predicated kernel; bit-identical results */
   GNX_OPT_GEMM_TILE_ROWS = 14,   /* 96 / 128: row-tile height of the pipelined tiled product (0: chosen per launch; bit-identical results) */
   GNX_OPT_GEMM_MID = 15,         /* 1: products with M < 4096 rows and <= 48 tiles of 128 x 128 run on 16 x 16 patches (k_gemm_mid) instead of the latency-bound tiled kernel */
-  GNX_OPT_COUNT = 16
+  GNX_OPT_SPLIT_AHEAD = 16,      /* gnx_pna_conv_fwd / _bwd split the weight images of their tiled products on side stream 2 at entry (GNX_GEMM_SPLIT_ONLY) instead of in front of each product: 1 = for layers with two or more towers (cfg-5: -0.44 ms per step; one tower: the fork / join costs what it saves), 2 = always, 0 = never */
+  GNX_OPT_COUNT = 17
 };
 int32_t gnx_set_option(gnx_handle* h, int32_t opt, int32_t value);
 int32_t gnx_get_option(gnx_handle* h, int32_t opt, int32_t* value);
@@ -177,7 +178,10 @@ typedef struct {
 enum {
   GNX_GEMM_RELU = 1,       /* C = max(.,0) */
   GNX_GEMM_ACCUMULATE = 2, /* C += (applied before relu; relu+accumulate is rejected) */
-  GNX_GEMM_B_TRANS = 4     /* NT */
+  GNX_GEMM_B_TRANS = 4,    /* NT */
+  GNX_GEMM_SPLIT_ONLY = 8, /* only write the split weight images this call would use into ws (nothing else is launched; a call that
+                              needs no images does nothing): lets the caller run the split ahead of the product, on another stream */
+  GNX_GEMM_PRESPLIT = 16   /* ws already holds those images (a GNX_GEMM_SPLIT_ONLY call with the same arguments) */
 };
 /* mask (optional, may be NULL): multiply the result by (mask[m*ldmask+n] > 0) — ReLU backward fused in dgrad.
  * ws / ws_bytes: caller-owned device scratch for the split weight images of the tiled split-operand kernel, size from
@@ -530,7 +534,7 @@ int32_t gnx_side_begin(gnx_handle* h);
 int32_t gnx_side_stream(gnx_handle* h, void** hip_stream);
 int32_t gnx_side_end(gnx_handle* h);
 int32_t gnx_side_join(gnx_handle* h);
-/* the same with an explicit side-stream index (0 or 1; gnx_side_begin / gnx_side_join are index 0).  Stream 1 carries
+/* the same with an explicit side-stream index (0, 1 or 2 -- 2 is used by gnx_pna_conv_fwd / _bwd themselves; gnx_side_begin / gnx_side_join are index 0).  Stream 1 carries
  * the bond-table gradient chain of a conv layer's backward (by-code segment sum -> 60-row products), which feeds only
  * parameter gradients and the bond-embedding gradient consumed at the very end of backward. */
 int32_t gnx_side_stream_n(gnx_handle* h, int32_t which, void** hip_stream);

@@ -41,6 +41,7 @@ VARIANTS = {
     "nofusedbwd": lambda dev: ops.set_option(dev, _lib.OPT_EDGE_FUSED, 2),
     "noas3": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_AS, 0),
     "nowsfast": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 0),
+    "nosplitahead": lambda dev: ops.set_option(dev, _lib.OPT_SPLIT_AHEAD, 0),
     "ws8waves": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1),
     "rcloop": lambda dev: ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 2),
     "rows128": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 128),
@@ -55,6 +56,7 @@ def reset(dev):
     ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
     ops.set_option(dev, _lib.OPT_EDGE_FUSED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_AS, 1)
+    ops.set_option(dev, _lib.OPT_SPLIT_AHEAD, 1)
     ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 1)
     ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 2)
     ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 0)
