@@ -3575,6 +3575,121 @@ __global__ void __launch_bounds__(256, 2) k_embed_bwd_mfma(embed_bwd_args g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same gradient on the bf16 matrix pipe (R <= 192 table rows, e.g. the 174 rows of the nine atom-feature tables):
+// the one-hot operand is EXACT in bf16 and is not computed but SCATTERED -- its [table row][batch row] LDS image stays
+// zero except for the K ones per batch row, which the thread that set them clears again after the multiply --, the
+// gradient goes through the three-piece split like every other product (three bf16 MFMAs per slab instead of eight
+// fp32 ones at a sixteenth of the rate: the fp32 kernel above spends 34 of its 107 us in the matrix pipe and most of the
+// rest building the one-hot operand with K x 4 compares per element).  A workgroup owns ALL table rows (six 32-row
+// blocks) x 128 channels (wave w: channels 32 w ..) of a row chunk; 32 batch rows per step; fp32 atomics at the end.
+// ---------------------------------------------------------------------------------------------------------------
+#define EB_R 192
+#define EB_LDX 80   // bytes per image row: 32 batch rows of bf16 + 16 (odd number of 16-byte slots)
+#define EB_X_BYTES (EB_R * EB_LDX)
+#define EB_Y_BYTES (128 * EB_LDX)
+__global__ void __launch_bounds__(256, 2) k_embed_bwd_bf16(embed_bwd_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[EB_X_BYTES];       // one-hot  [table row][32 batch rows]
+  __shared__ __attribute__((aligned(16))) unsigned char Ys[3 * EB_Y_BYTES];   // gradient [piece][channel][32 batch rows]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int c0 = blockIdx.y * 128;
+  const int64_t r_begin = (int64_t)blockIdx.x * g.rows_per_block;
+  int64_t r_end = r_begin + g.rows_per_block;
+  if (r_end > g.N) r_end = g.N;
+  if (r_begin >= r_end) return;
+
+  for (int i = tid; i < EB_X_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // (the first step's ones are set by other threads than the ones that zeroed their words)
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // gradient loader: thread = (channel, 16 batch rows): 4-byte loads, 256 contiguous bytes per wave instruction
+  const int yc = tid & 127, yh = tid >> 7;
+  const bool y_ok = c0 + yc < g.H;
+  // one-hot setter: work item = (batch row, feature): K <= 12 -> at most 384 items, two per thread at most
+  const int nitems = 32 * g.K;
+  int xpos[2] = {-1, -1};
+
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+    float yv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t row = r0 + 16 * yh + j;
+      yv[j] = (y_ok && row < r_end) ? g.Y[row * g.ldy + c0 + yc] : 0.f;
+    }
+    int fi[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int it = tid + 256 * q;
+      const int m = it / g.K, k = it - m * g.K;
+      const int64_t row = r0 + m;
+      fi[q] = -1;
+      if (it < nitems && row < r_end) {
+        const int f = (int)g.idx[row * g.K + k];
+        const int span = g.offs[k + 1] - g.offs[k];
+        if (f >= 0 && f < span) fi[q] = (g.offs[k] + f) * EB_LDX + m * 2;  // byte offset of X[table row][m]
+      }
+    }
+    {
+      bf16x8 pc[2][3];
+      float x8[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = yv[8 * hf + j];
+        split3(x8, pc[hf][0], pc[hf][1], pc[hf][2]);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        unsigned char* q = Ys + p * EB_Y_BYTES + yc * EB_LDX + 32 * yh;
+        *reinterpret_cast<bf16x8*>(q) = pc[0][p];
+        *reinterpret_cast<bf16x8*>(q + 16) = pc[1][p];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      xpos[q] = fi[q];
+      if (fi[q] >= 0) *reinterpret_cast<unsigned short*>(Xs + fi[q]) = 0x3F80;  // bf16 1.0
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        b[p] = *reinterpret_cast<const bf16x8*>(Ys + p * EB_Y_BYTES + (wave * 32 + li) * EB_LDX + 32 * sl + 16 * lh);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (i * 32 + li) * EB_LDX + 32 * sl + 16 * lh);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[2], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (xpos[q] >= 0) *reinterpret_cast<unsigned short*>(Xs + xpos[q]) = 0;  // (same thread that set it)
+  }
+  const int gc = c0 + wave * 32 + li;
+  if (gc < g.H) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[i][r];
+        if (gr < g.R && v != 0.f) atomicAdd(g.dT + (int64_t)gr * g.H + gc, v);
+      }
+  }
+}
+
 // returns GNX_OK after launching, or 1 if the shape is not eligible (caller falls back to the LDS-atomic kernel)
 int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, const int32_t* offsets, int R,
                            const float* dout, int H, float* dtable) {
@@ -3591,6 +3706,16 @@ int32_t gnx_embed_bwd_mfma(gnx_handle* h, const int64_t* idx, int64_t N, int K, 
   g.R = R;
   g.H = H;
   g.dT = dtable;
+  if (h->opt[GNX_OPT_EMBED_BWD_MFMA] == 1 && R <= EB_R) {  // (2 = the fp32-MFMA kernel below)
+    // ~256 workgroups; at least 128 rows each; small batches: ONE chunk per channel tile (one adder per element: deterministic)
+    int64_t rows = gnx_cdiv(gnx_cdiv(N, (int64_t)(N < 4096 ? 1 : 256)), 32) * 32;
+    if (rows < 128) rows = 128;
+    g.rows_per_block = rows;
+    dim3 grid((unsigned)gnx_cdiv(N, rows), (unsigned)gnx_cdiv(H, 128));
+    hipLaunchKernelGGL(k_embed_bwd_bf16, grid, dim3(256), 0, h->stream, g);
+    GNX_LAUNCH_CHECK();
+    return GNX_OK;
+  }
   const int64_t tiles = gnx_cdiv(R, BN) * gnx_cdiv(H, BN);
   int64_t chunks = gnx_cdiv(512, tiles);
   int64_t rows = gnx_cdiv(gnx_cdiv(N, chunks), BK) * BK;

@@ -62,7 +62,7 @@ enum {
   GNX_OPT_WGRAD_VEC = 3,         /* 0: element-wise weight-gradient loaders (debug) */
   GNX_OPT_WGRAD_WGS = 4,         /* > 0: target workgroup count of the weight-gradient kernels (default: #CUs) */
   GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
-  GNX_OPT_EMBED_BWD_MFMA = 6,    /* 1: atom-embedding gradient as a one-hot MFMA product for N >= 256 */
+  GNX_OPT_EMBED_BWD_MFMA = 6,    /* atom-embedding gradient as a one-hot MFMA product for N >= 256: 1 = scattered bf16 one-hot x three-piece gradient (tables of <= 192 rows), 2 = computed fp32 one-hot on the fp32 matrix pipe, 0 = LDS atomics */
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
   GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */

@@ -101,9 +101,22 @@ def test_gemm_ws_strided_views_and_guard_rows(gpu_device):
     assert float(out[:, :2 * F].abs().max()) == 0.0 and float(out[:, 3 * F:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("N,H", [(20000, 128), (9000, 36), (81920, 128), (640, 128), (300, 64)])
-def test_embed_backward_on_mfma(gpu_device, N, H):
-    """Large-batch AtomEncoder backward = one-hot^T x gradient on the matrix cores (exact 0/1 products)."""
+@pytest.mark.parametrize("kernel", [1, 2], ids=["bf16_scattered_one_hot", "fp32_computed_one_hot"])
+@pytest.mark.parametrize("N,H", [(20000, 128), (9000, 36), (81920, 128), (640, 128), (300, 64), (4097, 256)])
+def test_embed_backward_on_mfma(gpu_device, N, H, kernel):
+    """Large-batch AtomEncoder backward = one-hot^T x gradient on the matrix cores (exact 0/1 products): the bf16 kernel
+    (one-hot scattered into LDS, gradient as three bf16 pieces) and the fp32-MFMA kernel, ragged row counts, H below /
+    above one channel tile."""
+    import numpy as np
+    from gnnepcsaft_amd import nn as gnn, ops
+    ops.set_option(torch.device("cuda:0"), _lib.OPT_EMBED_BWD_MFMA, kernel)
+    try:
+        _embed_backward_case(gpu_device, N, H)
+    finally:
+        ops.set_option(torch.device("cuda:0"), _lib.OPT_EMBED_BWD_MFMA, 1)
+
+
+def _embed_backward_case(gpu_device, N, H):
     import numpy as np
     from gnnepcsaft_amd import nn as gnn
     from oracle import pyg_restatement as O

@@ -42,6 +42,7 @@ VARIANTS = {
     "noas3": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_AS, 0),
     "nowsfast": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 0),
     "nosplitahead": lambda dev: ops.set_option(dev, _lib.OPT_SPLIT_AHEAD, 0),
+    "embfp32": lambda dev: ops.set_option(dev, _lib.OPT_EMBED_BWD_MFMA, 2),
     "ws8waves": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1),
     "rcloop": lambda dev: ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 2),
     "rows128": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_TILE_ROWS, 128),
@@ -56,6 +57,7 @@ def reset(dev):
     ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
     ops.set_option(dev, _lib.OPT_EDGE_FUSED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_AS, 1)
+    ops.set_option(dev, _lib.OPT_EMBED_BWD_MFMA, 1)
     ops.set_option(dev, _lib.OPT_SPLIT_AHEAD, 1)
     ops.set_option(dev, _lib.OPT_AGG_BWD_RECOMPUTE, 1)
     ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 2)
