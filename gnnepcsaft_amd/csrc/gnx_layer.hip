@@ -158,7 +158,8 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   float* g = a->gbuf[gi];
   const float* z_last = a->zs[a->n_z - 1];
   int last_hidden;
-  const bool defer = a->defer_small != 0;  // small accumulators pre-zeroed by the caller, their consumers run in
+  const bool tail = (a->defer_small & 2) != 0;   // nothing follows this layer on the main stream (see the flush below)
+  const bool defer = (a->defer_small & 1) != 0;  // small accumulators pre-zeroed by the caller, their consumers run in
                                            // gnx_pna_stack_finish for all layers at once
   if (a->merged) {
     if (!defer) {
@@ -208,6 +209,9 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     }
   }
   const float* g_post0 = g;  // gradient w.r.t. post-layer 0's output: also an operand of dx below
+  // the last layer of the pass: the weight gradients queued so far (lin, hidden post layers, x part of post-layer 0) go out
+  // NOW, beside the edge backward, so that only the pre-layer ones are left for the end of the step
+  if (tail && side && (a->defer_small & 4) != 0) GNX_TRY(on_side(h, 0, side, [&]() -> int32_t { return wq.flush(h); }));
   // ---- scatter-aggregate backward, then the pre layers last..1
   int ei = 0;
   float* ge = a->gebuf[ei];
@@ -272,7 +276,13 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   }));
   // ---- the layer's weight gradients in batched launches on side stream 0, then what hangs off dWm
   GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
-    GNX_TRY(wq.flush(h));
+    // the LAST layer of a backward pass has the chip to itself: its batched weight gradients take every CU instead of the
+    // workgroup budget that leaves room for the main stream (the end of a step waits for exactly this launch)
+    const int wgs_saved = h->opt[GNX_OPT_WGRAD_WGS];
+    if (tail && wgs_saved == 0) h->opt[GNX_OPT_WGRAD_WGS] = h->num_cus > 0 ? h->num_cus : 256;
+    const int32_t fst = wq.flush(h);
+    h->opt[GNX_OPT_WGRAD_WGS] = wgs_saved;
+    GNX_TRY(fst);
     if (!a->merged || defer) return GNX_OK;
     const float* dbm = a->dbm;
     for (int t = 0; t < T; ++t) {

@@ -39,6 +39,15 @@ def prepare_ahead_enabled() -> bool:
 _BOND_CHAIN_ASIDE = True
 _NATIVE_LAYER_BWD = True
 _FUSED_EDGE = True
+_TAIL_WGRAD_ALL_CUS = True  # A/B switch: layer 0's batched weight gradients on every CU (tools/ab_bench.py notail)
+_TAIL_WGRAD_EARLY = False   # ... and its post-layer ones launched before the edge backward: measured 6.612 vs 6.554 ms (they
+#                             compete with the edge backward on the main stream), off
+
+
+def set_tail_wgrad_all_cus(on: bool, early: bool = False) -> None:
+    global _TAIL_WGRAD_ALL_CUS, _TAIL_WGRAD_EARLY
+    _TAIL_WGRAD_ALL_CUS, _TAIL_WGRAD_EARLY = bool(on), bool(early)
+
 _BATCH_WEIGHT_ONLY = True
 
 
@@ -621,6 +630,9 @@ def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_po
         a.dbm, o = base + 4 * o, o + H
         a.dWeff = base + 4 * o
         a.defer_small = 0
+    if ctx.layer_index == 0 and _TAIL_WGRAD_ALL_CUS:
+        a.defer_small |= 6 if _TAIL_WGRAD_EARLY else 2  # the last conv backward of the pass: its weight gradients may take
+        # every CU, and the ones of the post layers go out before the edge backward instead of at the end
     a.ws, a.ws_bytes, a.acc_buf, a.dx = ws.data_ptr(), ws_bytes, acc.buf.data_ptr(), dx.data_ptr()
     etiles = pack.edge_tiles(D - 1) if (_FUSED_EDGE and pre_layers == 2) else None  # (the forward's table, cached on the pack)
     a.etile_info, a.etile_w = (etiles[0].data_ptr(), etiles[1]) if etiles is not None else (None, 0)

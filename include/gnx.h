@@ -447,7 +447,10 @@ typedef struct {
   size_t ws_bytes;
   float* acc_buf;                             /* [R,H] bond-embedding gradient accumulator shared by the model's layers */
   float* dx;                                  /* [N,H] out: gradient w.r.t. the layer input */
-  int32_t defer_small;                        /* 1: dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
+  int32_t defer_small;                        /* bit 1 (value 2): this is the LAST conv backward of the pass (nothing follows on the
+                                                 main stream: its weight gradients may take every CU); bit 2 (value 4): ... and the ones queued before the
+                                                 edge backward are launched there instead of at the end.  bit 0 (value 1):
+                                                 dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
                                                  gnx_pna_stack_finish, which runs every layer's 60-row bond-table chain, its
                                                  lin o last-post un-merge and its Weff gradient in a few batched launches */
   int32_t etile_w;                            /* tile width of etile_info */
