@@ -1187,7 +1187,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
 //     conditional block makes the compiler's s_waitcnt insertion fall back to vmcnt(0), i.e. exposes the memory latency;
 //   * the second workgroup of the CU covers what one workgroup cannot hide: the LDS round trip behind the barrier,
 //     prologue, epilogue and tile switch.
-// Needs >= 4 K-tiles per output tile (the load cursor is at most one tile ahead of the multiply); used from 12.
+// Needs >= 4 K-tiles per output tile (the load cursor is at most one tile ahead of the multiply); used from 8.
 // Bit-identical to k_gemm3 (same MFMAs, same operands, same order per accumulator: tests/test_gemm_split_gpu.py).
 // Measured (tools/gemm3_diag.py, same box, us per launch, k_gemm3 -> k_gemm3p): post-layer 0 (K = 640) at 81 920 rows
 // 104 -> 97, at 131 072 rows 167 -> 151, at 655 360 rows 744 -> 643 (0.40 of the bf16 peak); K = 384 product 71.5 -> 62.7;
@@ -1198,7 +1198,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3(gemm_args g) {
 // workgroups; whole step (tools/ab_bench.py base / nopipe): cfg-2 7.75 vs 7.82 ms, cfg-4's batch 27.2 vs 27.5.
 // ---------------------------------------------------------------------------------------------------------------
 #define G3P_STAGES 2
-#define G3P_MIN_KTILES 12  // shorter K: the two-barrier kernel is as fast (measured at 4 and 8 K-tiles) and has the shorter prologue
+#define G3P_MIN_KTILES 8  // shorter K: the two-barrier kernel is as fast (measured at 4 K-tiles) and has the shorter prologue; at 8
+                         // K-tiles (cfg-3's 256-wide GINE layers, 327 680 rows) the pipelined kernel is worth 0.34 of the 19.4 ms step
 #define G3P_LDS(MI) (G3P_STAGES * 3 * 32 * (MI) * G3_LDB + 2 * 32 * (MI) * 4)
 
 // MI = 32-row blocks per tile (4: 128-row tiles; 3: 96-row tiles, taken when 128-row tiles leave the last round of the

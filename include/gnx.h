@@ -64,7 +64,7 @@ enum {
   GNX_OPT_AGG_BWD_RECOMPUTE = 5, /* 1: PNA aggregate backward recomputes mean/min/max/std from the messages */
   GNX_OPT_EMBED_BWD_MFMA = 6,    /* atom-embedding gradient as a one-hot MFMA product for N >= 256: 1 = scattered bf16 one-hot x three-piece gradient (tables of <= 192 rows), 2 = computed fp32 one-hot on the fp32 matrix pipe, 0 = LDS atomics */
   GNX_OPT_STD_BWD_CENTERED = 7,  /* 1: std gradient divides by the centred two-pass std (see gnx_pna_aggregate_bwd) */
-  GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 12 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
+  GNX_OPT_GEMM_PIPE = 8,         /* 1: tiled split products with >= 8 K-tiles per tile take the software-pipelined kernel (bit-identical results) */
   GNX_OPT_WGRAD_PIPE = 9,        /* 1: split weight gradients of 16-byte aligned operands through the software-pipelined kernel */
   GNX_OPT_EDGE_FUSED = 10,       /* 1: gnx_pna_conv_fwd / _bwd take the fused edge kernels (gnx_pna_edge_fwd / gnx_pna_edge_bwd) when eligible (bit-identical messages, h1, aggregate, gh1, dP); 2: forward only; 0: three launches each */
   GNX_OPT_SIDE_CUS = 11,         /* > 0: side stream 0 (weight gradients) is created with a CU mask of that many CUs (read when the stream is first used) */

@@ -112,7 +112,7 @@ def test_grouped_by_degree_class(gpu_device):
 
 
 def _both_tiled_kernels(fn):
-    """fn() through the software-pipelined kernel (default for >= 12 K-tiles) and through the two-barrier kernel."""
+    """fn() through the software-pipelined kernel (default for >= 8 K-tiles) and through the two-barrier kernel."""
     from gnnepcsaft_amd import ops
     outs = []
     for pipe in (1, 0):
