@@ -15,7 +15,7 @@ GNX_OK, GNX_E_INVALID, GNX_E_HIP, GNX_E_RANGE, GNX_E_WORKSPACE = 0, -1, -2, -3, 
 # gnx_set_option ids (include/gnx.h)
 OPT_GEMM_SPLIT, OPT_GEMM_WS, OPT_GEMM_VEC, OPT_WGRAD_VEC, OPT_WGRAD_WGS, OPT_AGG_BWD_RECOMPUTE, OPT_EMBED_BWD_MFMA, \
     OPT_STD_BWD_CENTERED, OPT_GEMM_PIPE, OPT_WGRAD_PIPE, OPT_EDGE_FUSED, OPT_SIDE_CUS, OPT_GEMM_AS, OPT_GEMM_WS_FAST, OPT_GEMM_TILE_ROWS, OPT_GEMM_MID, OPT_SPLIT_AHEAD = range(17)
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS = 1, 2, 4
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_B_TRANS, GEMM_SPLIT_ONLY, GEMM_PRESPLIT = 1, 2, 4, 8, 16
 POOL_ADD, POOL_MEAN, POOL_MAX = 0, 1, 2
 K_NONE, K_PNA_AGG_FWD, K_PNA_AGG_BWD, K_GEMM_WS, K_GEMM_WGRAD, K_GINE_AGG_FWD, K_GINE_AGG_BWD, K_EDGE_COMBINE_FWD, \
     K_EDGE_COMBINE_BWD, K_BN_FWD, K_BN_BWD, K_GEMM_TILED, K_GEMM_SMALL, K_GEMM_WGRAD_BATCHED, K_KEY_SEGMENT_SUM, \

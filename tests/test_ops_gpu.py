@@ -633,3 +633,21 @@ def test_options_and_caller_owned_gemm_workspace(gpu_device):
     assert st == _lib.GNX_E_WORKSPACE
     # a product the split path does not take needs no workspace
     assert lib.gnx_gemm_workspace_bytes(h, 1, seg, None, 1, 1000, N, None, _lib.GEMM_B_TRANS, 0) == 0
+    # the split on its own (GNX_GEMM_SPLIT_ONLY: e.g. ahead of time on another stream), then the product on the images as
+    # they are (GNX_GEMM_PRESPLIT): the same bits as the plain call; SPLIT_ONLY touches nothing but the workspace
+    ws2 = torch.zeros(need, dtype=torch.uint8, device=gpu_device)
+    out3 = torch.full((M, N), float("nan"), device=gpu_device)
+    _lib.check(lib.gnx_gemm(h, 1, seg, M, N, None, None, 0, out3.data_ptr(), N, _lib.GEMM_B_TRANS | _lib.GEMM_SPLIT_ONLY,
+                            ws2.data_ptr(), need))
+    assert torch.isnan(out3).all() and torch.equal(ws2, ws)
+    _lib.check(lib.gnx_gemm(h, 1, seg, M, N, None, None, 0, out3.data_ptr(), N, _lib.GEMM_B_TRANS | _lib.GEMM_PRESPLIT,
+                            ws2.data_ptr(), need))
+    assert torch.equal(out3, out2)
+    # SPLIT_ONLY on a call that needs no images (weights-stationary shape) does nothing at all
+    a2, w2 = torch.randn(9000, 128, device=gpu_device), torch.randn(128, 128, device=gpu_device)
+    seg2 = (_lib.GemmSeg * 1)()
+    seg2[0].a, seg2[0].lda, seg2[0].rowscale, seg2[0].b, seg2[0].ldb, seg2[0].k = a2.data_ptr(), 128, None, w2.data_ptr(), 128, 128
+    out4 = torch.full((9000, 128), float("nan"), device=gpu_device)
+    _lib.check(lib.gnx_gemm(h, 1, seg2, 9000, 128, None, None, 0, out4.data_ptr(), 128, _lib.GEMM_B_TRANS | _lib.GEMM_SPLIT_ONLY,
+                            None, 0))
+    assert torch.isnan(out4).all()
