@@ -159,6 +159,8 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   const float* z_last = a->zs[a->n_z - 1];
   int last_hidden;
   const bool tail = (a->defer_small & 2) != 0;   // nothing follows this layer on the main stream (see the flush below)
+  const bool class_after_agg = (a->defer_small & 8) != 0 && side;  // per-class weight gradient forked behind the aggregate backward
+  std::vector<std::function<int32_t()>> class_wgrads;
   const bool defer = (a->defer_small & 1) != 0;  // small accumulators pre-zeroed by the caller, their consumers run in
                                            // gnx_pna_stack_finish for all layers at once
   if (a->merged) {
@@ -196,11 +198,15 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     wq.add(gt, H, a->x + t * F, H, N, F, F, dWp, 13 * F, G[k + 1]);
     float* dWeff = a->dWeff + (int64_t)t * D * F * 4 * F;
     if (!defer) GNX_TRY(gnx_fill(h, dWeff, (int64_t)D * F * 4 * F, 0.f));
-    GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
+    auto class_wgrad = [&, gt, At, dWeff, dWp]() -> int32_t {
       GNX_TRY(gnx_gemm_wgrad_grouped(h, gt, H, At, (int64_t)T * 4 * F, N, F, 4 * F, dWeff, 4 * F, (int64_t)F * 4 * F, a->dperm,
                                      a->chunks, a->nchunks, a->max_chunks));
       return defer ? GNX_OK : gnx_pna_weff_bwd(h, dWeff, F, D, a->avg_deg_log, dWp, 13 * F);
-    }));
+    };
+    if (class_after_agg)
+      class_wgrads.push_back(class_wgrad);
+    else
+      GNX_TRY(on_side(h, 0, side, class_wgrad));
     if (ahead) {
       if (t == 0) GNX_TRY(gnx_side_join_n(h, 2));
       GNX_TRY(dA_call(t, gt, GNX_GEMM_PRESPLIT, ahead_base + (size_t)t * (r_dA + r_dx), r_dA));
@@ -216,6 +222,7 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   int ei = 0;
   float* ge = a->gebuf[ei];
   GNX_TRY(gnx_pna_aggregate_bwd(h, a->dA, a->hs[a->n_h - 1], a->A, a->rowptr, N, E, T, F, ge));
+  for (auto& fn : class_wgrads) GNX_TRY(on_side(h, 0, side, fn));
   // With two pre layers (the reference's default) the masked input gradient of pre-layer 1, the destination sums dP and the
   // bond-table sums dTe come from ONE pass over the message gradient (gnx_pna_edge_bwd); only dQ is a pass of its own.
   bool fused_bwd = h->opt[GNX_OPT_EDGE_FUSED] == 1 && pre == 2 && a->etile_info != nullptr && E > 0 && F % 4 == 0 && F <= 128 &&

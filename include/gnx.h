@@ -449,7 +449,9 @@ typedef struct {
   float* dx;                                  /* [N,H] out: gradient w.r.t. the layer input */
   int32_t defer_small;                        /* bit 1 (value 2): this is the LAST conv backward of the pass (nothing follows on the
                                                  main stream: its weight gradients may take every CU); bit 2 (value 4): ... and the ones queued before the
-                                                 edge backward are launched there instead of at the end.  bit 0 (value 1):
+                                                 edge backward are launched there instead of at the end; bit 3 (value 8): the per-class weight
+                                                 gradient of post-layer 0 is forked BEHIND the aggregate backward (a memory-bound kernel it
+                                                 slows down a lot: 135 us beside it, 55 alone) instead of in front of it.  bit 0 (value 1):
                                                  dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
                                                  gnx_pna_stack_finish, which runs every layer's 60-row bond-table chain, its
                                                  lin o last-post un-merge and its Weff gradient in a few batched launches */

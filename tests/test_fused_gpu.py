@@ -171,8 +171,10 @@ def test_model_with_and_without_the_fused_edge_kernel(gpu_device, name):
         assert rel_err(p1, p0) <= 5e-3 and rel_err(l1, l0) <= 1e-3
     G = max(float(v.abs().max()) for v in g0.values())
     for n in g0:
-        # (fp32 atomics of the weight gradients arrive in another order every run: 1e-4 of 1 % of the largest entry)
-        assert rel_err(g1[n], g0[n], floor=1e-2 * G) <= (1e-4 if big else 0.2), n
+        # (fp32 atomics of the weight gradients arrive in another order every run: REPEATS of one configuration differ by up
+        # to 8.8e-5 in this metric over 30 runs -- tools/atomics_noise.py, worst on the lin biases, whose gradient in front of
+        # BatchNorm is analytically zero, i.e. pure cancellation -- so 1e-4 failed once in a while; a missing launch shows at 1e-1)
+        assert rel_err(g1[n], g0[n], floor=1e-2 * G) <= (1e-3 if big else 0.2), n
 
 
 @pytest.mark.parametrize("name", ["pna_small", "pna_towers4", "pna_cfg2_shape_256", "pna_pre1_post1", "pna_hubs"])
