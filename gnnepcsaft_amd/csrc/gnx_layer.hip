@@ -258,6 +258,21 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
     float* dW0 = G[pidx(t, true, 0)];
     wq.add(a->dP + t * F, H, a->x + t * F, H, N, F, F, dW0, 3 * F, nullptr);
     wq.add(a->dQ + t * F, H, a->x + t * F, H, N, F, F, dW0 + F, 3 * F, nullptr);
+  }
+  // the queue is complete: with defer_small bit 4 the batched weight gradients start HERE, beside the dx product (matrix-
+  // bound), instead of behind it, beside the next layer's BatchNorm backward (memory-bound)
+  auto flush_batched = [&]() -> int32_t {
+    // the LAST layer of a backward pass has the chip to itself: its batched weight gradients take every CU instead of the
+    // workgroup budget that leaves room for the main stream (the end of a step waits for exactly this launch)
+    const int wgs_saved = h->opt[GNX_OPT_WGRAD_WGS];
+    if (tail && wgs_saved == 0) h->opt[GNX_OPT_WGRAD_WGS] = h->num_cus > 0 ? h->num_cus : 256;
+    const int32_t fst = wq.flush(h);
+    h->opt[GNX_OPT_WGRAD_WGS] = wgs_saved;
+    return fst;
+  };
+  const bool flush_before_dx = (a->defer_small & 16) != 0 && side && !tail;
+  if (flush_before_dx) GNX_TRY(on_side(h, 0, side, flush_batched));
+  for (int t = 0; t < T; ++t) {
     if (ahead)
       GNX_TRY(dx_call(t, g_post0, GNX_GEMM_PRESPLIT, ahead_base + (size_t)t * (r_dA + r_dx) + r_dA, r_dx));
     else
@@ -283,13 +298,7 @@ extern "C" int32_t gnx_pna_conv_bwd(gnx_handle* h, const gnx_pna_bwd_args* a) {
   }));
   // ---- the layer's weight gradients in batched launches on side stream 0, then what hangs off dWm
   GNX_TRY(on_side(h, 0, side, [&]() -> int32_t {
-    // the LAST layer of a backward pass has the chip to itself: its batched weight gradients take every CU instead of the
-    // workgroup budget that leaves room for the main stream (the end of a step waits for exactly this launch)
-    const int wgs_saved = h->opt[GNX_OPT_WGRAD_WGS];
-    if (tail && wgs_saved == 0) h->opt[GNX_OPT_WGRAD_WGS] = h->num_cus > 0 ? h->num_cus : 256;
-    const int32_t fst = wq.flush(h);
-    h->opt[GNX_OPT_WGRAD_WGS] = wgs_saved;
-    GNX_TRY(fst);
+    if (!flush_before_dx) GNX_TRY(flush_batched());
     if (!a->merged || defer) return GNX_OK;
     const float* dbm = a->dbm;
     for (int t = 0; t < T; ++t) {

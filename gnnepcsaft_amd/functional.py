@@ -41,6 +41,8 @@ _NATIVE_LAYER_BWD = True
 _FUSED_EDGE = True
 _CLASS_WGRAD_AFTER_AGG = True  # the per-class weight gradient starts behind the aggregate backward, not beside it: 6.640 -> 6.609 ms,
 #                                cfg-5 55.88 -> 55.63 (tools/ab_bench.py classearly); at the END of the layer it was worse (6.662 vs 6.579)
+_WGRAD_FLUSH_BEFORE_DX = True  # the batched weight gradients of a layer start in front of its dx product: 6.578 -> 6.541 ms, cfg-5
+#                                56.03 -> 55.90 (tools/ab_bench.py flushlate)
 _TAIL_WGRAD_ALL_CUS = True  # A/B switch: layer 0's batched weight gradients on every CU (tools/ab_bench.py notail)
 _TAIL_WGRAD_EARLY = False   # ... and its post-layer ones launched before the edge backward: measured 6.612 vs 6.554 ms (they
 #                             compete with the edge backward on the main stream), off
@@ -49,6 +51,11 @@ _TAIL_WGRAD_EARLY = False   # ... and its post-layer ones launched before the ed
 def set_class_wgrad_after_agg(on: bool) -> None:
     global _CLASS_WGRAD_AFTER_AGG
     _CLASS_WGRAD_AFTER_AGG = bool(on)
+
+
+def set_wgrad_flush_before_dx(on: bool) -> None:
+    global _WGRAD_FLUSH_BEFORE_DX
+    _WGRAD_FLUSH_BEFORE_DX = bool(on)
 
 
 def set_tail_wgrad_all_cus(on: bool, early: bool = False) -> None:
@@ -639,6 +646,8 @@ def _pna_backward_native(ctx, dout, x, BE, EE, A, hs, zs, params, sinks, code_po
         a.defer_small = 0
     if _CLASS_WGRAD_AFTER_AGG:
         a.defer_small |= 8
+    if _WGRAD_FLUSH_BEFORE_DX:
+        a.defer_small |= 16
     if ctx.layer_index == 0 and _TAIL_WGRAD_ALL_CUS:
         a.defer_small |= 6 if _TAIL_WGRAD_EARLY else 2  # the last conv backward of the pass: its weight gradients may take
         # every CU, and the ones of the post layers go out before the edge backward instead of at the end

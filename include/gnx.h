@@ -451,7 +451,9 @@ typedef struct {
                                                  main stream: its weight gradients may take every CU); bit 2 (value 4): ... and the ones queued before the
                                                  edge backward are launched there instead of at the end; bit 3 (value 8): the per-class weight
                                                  gradient of post-layer 0 is forked BEHIND the aggregate backward (a memory-bound kernel it
-                                                 slows down a lot: 135 us beside it, 55 alone) instead of in front of it.  bit 0 (value 1):
+                                                 slows down a lot: 135 us beside it, 55 alone) instead of in front of it; bit 4 (value 16): the
+                                                 batched weight gradients start in front of the dx product (matrix-bound) instead of behind it
+                                                 (beside the next layer's BatchNorm backward).  bit 0 (value 1):
                                                  dTe / dEE / dWm / dbm / dWeff were ZEROED by the caller and stay alive until
                                                  gnx_pna_stack_finish, which runs every layer's 60-row bond-table chain, its
                                                  lin o last-post un-merge and its Weff gradient in a few batched launches */

@@ -44,6 +44,7 @@ VARIANTS = {
     "nosplitahead": lambda dev: ops.set_option(dev, _lib.OPT_SPLIT_AHEAD, 0),
     "embfp32": lambda dev: ops.set_option(dev, _lib.OPT_EMBED_BWD_MFMA, 2),
     "classearly": lambda dev: Fn.set_class_wgrad_after_agg(False),
+    "flushlate": lambda dev: Fn.set_wgrad_flush_before_dx(False),
     "notail": lambda dev: Fn.set_tail_wgrad_all_cus(False),
     "tailearly": lambda dev: Fn.set_tail_wgrad_all_cus(True, True),
     "ws8waves": lambda dev: ops.set_option(dev, _lib.OPT_GEMM_WS_FAST, 1),
@@ -54,7 +55,7 @@ VARIANTS = {
 
 
 def reset(dev):
-    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True); Fn.set_fused_edge(True); Fn.set_batch_weight_only(True); Fn.set_tail_wgrad_all_cus(True); Fn.set_class_wgrad_after_agg(True)
+    Fn.set_merge_last_post(True); Fn.set_prepare_ahead(True); Fn.set_bond_chain_aside(True); Fn.set_native_layer_backward(True); ops.set_wgrad_side_stream(True); Fn.set_fused_edge(True); Fn.set_batch_weight_only(True); Fn.set_tail_wgrad_all_cus(True); Fn.set_class_wgrad_after_agg(True); Fn.set_wgrad_flush_before_dx(True)
     ops.set_option(dev, _lib.OPT_STD_BWD_CENTERED, 1)
     ops.set_option(dev, _lib.OPT_GEMM_PIPE, 1)
     ops.set_option(dev, _lib.OPT_WGRAD_PIPE, 1)
